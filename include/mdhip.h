@@ -1,0 +1,229 @@
+/*
+ * mdhip.h — C-ABI of libmdhip.so, the MI355X (gfx950) array runtime that sits
+ * behind minidiff's backend boundary.
+ *
+ * Every entry point below replaces one group of names in the reference's
+ * backend function table (reference: minidiff/backend/numpy.py:14-206, the
+ * alias table onto NumPy; abstract surface minidiff/backend/__init__.py:88-759).
+ * The reference has no FFI of its own: its "binding" is a Python class whose
+ * attributes are array functions, so the C boundary is what a ctypes shim
+ * (minidiff_amd/hip_backend.py) needs in order to serve those attributes.
+ * INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *  - plain C: pointers, sizes, PODs; no C++ / torch types cross this line.
+ *  - every function returns an int status (MDHIP_OK or an MDHIP_E* code that
+ *    the shim maps onto ValueError / TypeError / IndexError / MemoryError /
+ *    RuntimeError, mirroring the exception types NumPy raises for the
+ *    reference); mdhip_last_error() returns the thread-local message.
+ *  - all device work is enqueued on ONE stream per process (the reference is
+ *    single-threaded eager: stream order == program order); only the calls
+ *    documented as synchronising wait for the device.
+ *  - arrays are described by value with mdhip_array: a device pointer to the
+ *    element at index (0,...,0), a dtype code, and shape/strides in ELEMENTS
+ *    (strides may be 0 for broadcast views or negative for flipped views).
+ *  - Python scalars travel as mdhip_array with is_scalar != 0 (no device
+ *    memory; value in scalar_f / scalar_i), which keeps NumPy's weak-scalar
+ *    promotion in the caller and the arithmetic on the device.
+ */
+#ifndef MDHIP_H
+#define MDHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDHIP_MAX_NDIM 8
+
+/* ---- status codes -------------------------------------------------------- */
+enum {
+  MDHIP_OK = 0,
+  MDHIP_EVALUE = 1,   /* -> ValueError  */
+  MDHIP_ETYPE = 2,    /* -> TypeError   */
+  MDHIP_EINDEX = 3,   /* -> IndexError  */
+  MDHIP_EMEMORY = 4,  /* -> MemoryError */
+  MDHIP_ERUNTIME = 5  /* -> RuntimeError (HIP / RCCL failure) */
+};
+
+/* ---- dtypes (reference: minidiff/backend/numpy.py:188-200) --------------- */
+enum {
+  MDHIP_BOOL = 0, /* 1 byte, values 0/1 (numpy.bool_) */
+  MDHIP_I32 = 1,
+  MDHIP_I64 = 2,
+  MDHIP_F32 = 3,
+  MDHIP_F64 = 4,
+  MDHIP_NUM_DTYPES = 5
+};
+
+typedef struct mdhip_array {
+  void *data;                       /* device pointer (NULL when is_scalar) */
+  int32_t dtype;                    /* MDHIP_* dtype code */
+  int32_t ndim;                     /* 0..MDHIP_MAX_NDIM */
+  int64_t shape[MDHIP_MAX_NDIM];
+  int64_t strides[MDHIP_MAX_NDIM];  /* in elements */
+  int32_t is_scalar;                /* host scalar operand */
+  int32_t _pad;
+  int64_t scalar_i;                 /* value when dtype is BOOL/I32/I64 */
+  double scalar_f;                  /* value when dtype is F32/F64 */
+} mdhip_array;
+
+/* ---- unary ops (reference: numpy.py:19-59; definitions.py:266-420) ------- */
+enum {
+  MDHIP_U_COPY = 0, /* copy / astype: out dtype may differ from in dtype */
+  MDHIP_U_ABS,
+  MDHIP_U_NEG,
+  MDHIP_U_SIGN,
+  MDHIP_U_CEIL,
+  MDHIP_U_FLOOR,
+  MDHIP_U_SIN,
+  MDHIP_U_COS,
+  MDHIP_U_TAN,
+  MDHIP_U_SINH,
+  MDHIP_U_COSH,
+  MDHIP_U_TANH,
+  MDHIP_U_EXP,
+  MDHIP_U_LOG,
+  MDHIP_U_SQRT,
+  MDHIP_U_LOGICAL_NOT,
+  MDHIP_U_INVERT,
+  MDHIP_U_ISNAN,
+  MDHIP_U_COUNT
+};
+
+/* ---- binary ops (reference: numpy.py:61-92; definitions.py:424-536) ------ */
+enum {
+  MDHIP_B_ADD = 0,
+  MDHIP_B_SUB,
+  MDHIP_B_MUL,
+  MDHIP_B_TRUE_DIV,
+  MDHIP_B_FLOOR_DIV,
+  MDHIP_B_MOD,
+  MDHIP_B_POW,
+  MDHIP_B_MAXIMUM,
+  MDHIP_B_MINIMUM,
+  MDHIP_B_EQ,
+  MDHIP_B_NE,
+  MDHIP_B_LT,
+  MDHIP_B_LE,
+  MDHIP_B_GT,
+  MDHIP_B_GE,
+  MDHIP_B_LAND,
+  MDHIP_B_LOR,
+  MDHIP_B_LXOR,
+  MDHIP_B_COUNT
+};
+
+/* ---- reductions (reference: numpy.py:20-23,43-46,56-57) ------------------ */
+enum {
+  MDHIP_R_SUM = 0,
+  MDHIP_R_PROD,
+  MDHIP_R_MAX,
+  MDHIP_R_MIN,
+  MDHIP_R_ANY,
+  MDHIP_R_ALL,
+  MDHIP_R_ARGMAX,
+  MDHIP_R_ARGMIN,
+  MDHIP_R_COUNT
+};
+
+/* ======================= runtime ========================================== */
+/* Bind this process to HIP device `device`, create the stream and the caching
+ * allocator. Idempotent for the same device. */
+int mdhip_init(int device);
+int mdhip_device(int *device_out);
+/* "hip:gfx950" for the product library; the CPU test double under oracle/
+ * answers "host". The shim refuses to run product code on anything else. */
+const char *mdhip_target(void);
+const char *mdhip_last_error(void);
+/* Device-memory blocks come from a size-binned caching allocator (the tape
+ * frees temporaries by Python refcount: SURVEY.md §5 "Memory management"). */
+int mdhip_alloc(size_t nbytes, void **ptr_out);
+int mdhip_free(void *ptr);
+int mdhip_empty_cache(void);
+/* stats[0]=bytes in use, [1]=bytes cached, [2]=peak in use, [3]=#hipMalloc */
+int mdhip_mem_stats(int64_t stats[4]);
+int mdhip_h2d(void *dst, const void *src, size_t nbytes); /* async on stream for pinned src; ordered */
+int mdhip_d2h(void *dst, const void *src, size_t nbytes); /* SYNCHRONISES */
+int mdhip_d2d(void *dst, const void *src, size_t nbytes); /* async */
+int mdhip_sync(void);                                     /* stream + device */
+/* HIP events on the library's stream, for bench.py's per-kernel timing. */
+int mdhip_event_create(void **ev_out);
+int mdhip_event_record(void *ev);
+int mdhip_event_elapsed_ms(void *start, void *stop, float *ms_out); /* SYNCHRONISES on stop */
+int mdhip_event_destroy(void *ev);
+
+/* ======================= elementwise ====================================== */
+/* out = op(x). `out` describes freshly allocated (or in-place) memory with the
+ * result dtype chosen by the caller from NumPy's type resolution. */
+int mdhip_unary(int op, const mdhip_array *x, const mdhip_array *out);
+/* out = op(a, b) with NumPy broadcasting already applied by the caller:
+ * a, b and out have the same ndim/shape; broadcast axes carry stride 0.
+ * compute_dtype = the ufunc loop dtype NumPy resolves (np.<op>.resolve_dtypes). */
+int mdhip_binary(int op, const mdhip_array *a, const mdhip_array *b,
+                 const mdhip_array *out, int compute_dtype);
+/* out = cond ? a : b            (reference: numpy.py:95, definitions.py:555-559) */
+int mdhip_where(const mdhip_array *cond, const mdhip_array *a, const mdhip_array *b,
+                const mdhip_array *out);
+/* fill out with a scalar (ones/zeros/full families, numpy.py:98-103) */
+int mdhip_fill(const mdhip_array *out, const mdhip_array *scalar);
+/* out[i] = start + i*step (numpy.py:125 arange) */
+int mdhip_arange(const mdhip_array *out, double start, double step);
+
+/* ======================= reductions ======================================= */
+/* Reduce x over the axes whose bit is set in axis_mask. `out` has x's ndim
+ * with reduced axes of extent 1 (the caller drops them for keepdims=False).
+ * SUM/PROD accumulate in out's dtype; ARG* write int64 flat positions along
+ * the (single, or fully flattened) reduced extent.
+ * (reference: numpy.py:20-23,43-46,57; reduce-to-shape definitions.py:157-183) */
+int mdhip_reduce(int op, const mdhip_array *x, const mdhip_array *out, uint32_t axis_mask);
+
+/* ======================= matmul =========================================== */
+/* C[b] = A[b] @ B[b]: A (batch.., M, K), B (batch.., K, N), C (batch.., M, N),
+ * any strides (NN / NT / TN arrive as strided views: definitions.py:487-492).
+ * Arrays are passed 3-D (batch, rows, cols); batch stride 0 broadcasts.
+ * f32 and f64 run on MFMA; other dtypes take the generic kernel. */
+int mdhip_matmul(const mdhip_array *a, const mdhip_array *b, const mdhip_array *c);
+
+/* ======================= indexing (bit-exact) ============================= */
+/* Generalised gather/scatter over an "indexed view":
+ *   offset(p) = sum_d p[d]*src_strides[d]
+ *             + sum_k wrap(idx_k[ sum_d p[d]*idx_strides[k][d] ], idx_extent[k]) * idx_mult[k]
+ * for every position p of `shape[ndim]`. Covers a[key] with integer-array keys,
+ * take_along_axis / put_along_axis, a[key] = v, and np.add.at.
+ * (reference: numpy.py:73-75,105,108,124; definitions.py:186-189) */
+typedef struct mdhip_index_plan {
+  int32_t ndim;
+  int32_t n_idx;
+  int64_t shape[MDHIP_MAX_NDIM];
+  int64_t src_strides[MDHIP_MAX_NDIM];
+  const void *idx_ptr[MDHIP_MAX_NDIM];
+  int32_t idx_dtype[MDHIP_MAX_NDIM];              /* MDHIP_I32 / MDHIP_I64 */
+  int64_t idx_extent[MDHIP_MAX_NDIM];             /* axis length for wrap + bounds */
+  int64_t idx_mult[MDHIP_MAX_NDIM];               /* source stride of that axis */
+  int64_t idx_strides[MDHIP_MAX_NDIM][MDHIP_MAX_NDIM];
+} mdhip_index_plan;
+enum { MDHIP_SCATTER_SET = 0, MDHIP_SCATTER_ADD = 1 };
+/* out[p] = src[offset(p)]; out is contiguous-or-strided with plan->shape. */
+int mdhip_gather(const mdhip_index_plan *plan, const void *src, int dtype,
+                 const mdhip_array *out);
+/* dst[offset(p)] (=|+=) val[p]; duplicates accumulate in p order for ADD (the
+ * np.add.at contract), last p wins for SET. Out-of-range -> MDHIP_EINDEX. */
+int mdhip_scatter(const mdhip_index_plan *plan, void *dst, int dtype,
+                  const mdhip_array *val, int mode);
+
+/* ======================= data-parallel (RCCL over xGMI) =================== */
+/* One communicator per process (one process per GPU). uid is the 128-byte
+ * ncclUniqueId produced on rank 0 and distributed by the launcher. */
+#define MDHIP_UID_BYTES 128
+int mdhip_comm_get_unique_id(uint8_t uid[MDHIP_UID_BYTES]);
+int mdhip_comm_init(int nranks, int rank, const uint8_t uid[MDHIP_UID_BYTES]);
+int mdhip_comm_allreduce_sum(void *buf, size_t count, int dtype); /* in place, on the stream */
+int mdhip_comm_destroy(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDHIP_H */

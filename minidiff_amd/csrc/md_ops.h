@@ -1,0 +1,380 @@
+// md_ops.h — scalar semantics of every elementwise / reduction operator.
+//
+// One definition, two compilations: hipcc builds these functors into the gfx950
+// kernels (minidiff_amd/csrc/*.hip); g++ builds them into the CPU test double
+// under oracle/host_target/. What they restate is the per-element behaviour of
+// the NumPy ufunc each reference backend name aliases
+// (reference: minidiff/backend/numpy.py:19-95). NumPy's documented inner-loop
+// rules that matter here: Python-style floor_divide/remainder (sign of the
+// divisor), integer power by repeated squaring with wrap-around, NaN-propagating
+// maximum/minimum, sign(NaN)=NaN, integer division by zero -> 0.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#if defined(__HIPCC__)
+#define MD_HD __host__ __device__ __forceinline__
+#else
+#define MD_HD inline
+#endif
+
+// numpy.bool_ : one byte holding 0 or 1. A distinct type so that conversions to
+// and from it normalise (x != 0) instead of truncating.
+struct b8 {
+  uint8_t v;
+};
+
+template <class T> struct md_is_float { static constexpr bool value = false; };
+template <> struct md_is_float<float> { static constexpr bool value = true; };
+template <> struct md_is_float<double> { static constexpr bool value = true; };
+
+template <class To, class From> struct md_caster {
+  static MD_HD To run(From x) { return (To)x; }
+};
+template <class From> struct md_caster<b8, From> {
+  static MD_HD b8 run(From x) { return b8{(uint8_t)(x != (From)0)}; }
+};
+template <class To> struct md_caster<To, b8> {
+  static MD_HD To run(b8 x) { return (To)x.v; }
+};
+template <> struct md_caster<b8, b8> {
+  static MD_HD b8 run(b8 x) { return x; }
+};
+// float -> integer casts of out-of-range / NaN values are UB in C; NumPy yields
+// INT_MIN on x86. Pin that so host double and device agree.
+template <> struct md_caster<int64_t, double> {
+  static MD_HD int64_t run(double x) {
+    if (!(x >= -9223372036854775808.0 && x < 9223372036854775808.0)) return INT64_MIN;
+    return (int64_t)x;
+  }
+};
+template <> struct md_caster<int64_t, float> {
+  static MD_HD int64_t run(float x) { return md_caster<int64_t, double>::run((double)x); }
+};
+template <> struct md_caster<int32_t, double> {
+  static MD_HD int32_t run(double x) {
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return INT32_MIN;
+    return (int32_t)x;
+  }
+};
+template <> struct md_caster<int32_t, float> {
+  static MD_HD int32_t run(float x) { return md_caster<int32_t, double>::run((double)x); }
+};
+template <class To, class From> MD_HD To md_cast(From x) { return md_caster<To, From>::run(x); }
+
+// ---- math wrappers so f32 stays f32 (OCML accurate versions on device) -------
+#define MD_MATH1(name, ffn, dfn)                   \
+  MD_HD float md_##name(float x) { return ffn(x); } \
+  MD_HD double md_##name(double x) { return dfn(x); }
+MD_MATH1(sin, sinf, sin)
+MD_MATH1(cos, cosf, cos)
+MD_MATH1(tan, tanf, tan)
+MD_MATH1(sinh, sinhf, sinh)
+MD_MATH1(cosh, coshf, cosh)
+MD_MATH1(tanh, tanhf, tanh)
+MD_MATH1(exp, expf, exp)
+MD_MATH1(log, logf, log)
+MD_MATH1(sqrt, sqrtf, sqrt)
+MD_MATH1(ceil, ceilf, ceil)
+MD_MATH1(floor, floorf, floor)
+MD_MATH1(fabs, fabsf, fabs)
+#undef MD_MATH1
+MD_HD float md_fmod(float a, float b) { return fmodf(a, b); }
+MD_HD double md_fmod(double a, double b) { return fmod(a, b); }
+MD_HD float md_pow(float a, float b) { return powf(a, b); }
+MD_HD double md_pow(double a, double b) { return pow(a, b); }
+MD_HD float md_copysign(float a, float b) { return copysignf(a, b); }
+MD_HD double md_copysign(double a, double b) { return copysign(a, b); }
+MD_HD bool md_isnan(float x) { return x != x; }
+MD_HD bool md_isnan(double x) { return x != x; }
+template <class T> MD_HD bool md_isnan(T) { return false; }
+
+// ============================ unary ===========================================
+// apply<T>(x) -> T unless the functor declares a bool result (returns b8).
+struct UCopy {
+  template <class T> static MD_HD T apply(T x) { return x; }
+};
+struct UAbs {
+  template <class T> static MD_HD T apply(T x) {
+    if constexpr (md_is_float<T>::value) {
+      return md_fabs(x);
+    } else if constexpr (sizeof(T) == 1) {
+      return x;
+    } else {
+      using U = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;
+      return x < 0 ? (T)((U)0 - (U)x) : x;
+    }
+  }
+};
+struct UNeg {
+  template <class T> static MD_HD T apply(T x) {
+    if constexpr (md_is_float<T>::value) {
+      return -x;
+    } else {
+      using U = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;
+      return (T)((U)0 - (U)x);
+    }
+  }
+};
+struct USign {
+  template <class T> static MD_HD T apply(T x) {
+    if constexpr (md_is_float<T>::value) {
+      if (x != x) return x;
+      return (T)((x > (T)0) - (x < (T)0));
+    } else {
+      return (T)((x > (T)0) - (x < (T)0));
+    }
+  }
+};
+struct UCeil {
+  template <class T> static MD_HD T apply(T x) {
+    if constexpr (md_is_float<T>::value) return md_ceil(x);
+    else return x;
+  }
+};
+struct UFloor {
+  template <class T> static MD_HD T apply(T x) {
+    if constexpr (md_is_float<T>::value) return md_floor(x);
+    else return x;
+  }
+};
+#define MD_UFLOAT(Name, fn)                                        \
+  struct Name {                                                    \
+    template <class T> static MD_HD T apply(T x) { return fn(x); } \
+  };
+MD_UFLOAT(USin, md_sin)
+MD_UFLOAT(UCos, md_cos)
+MD_UFLOAT(UTan, md_tan)
+MD_UFLOAT(USinh, md_sinh)
+MD_UFLOAT(UCosh, md_cosh)
+MD_UFLOAT(UTanh, md_tanh)
+MD_UFLOAT(UExp, md_exp)
+MD_UFLOAT(ULog, md_log)
+MD_UFLOAT(USqrt, md_sqrt)
+#undef MD_UFLOAT
+struct UInvert {  // integers: bitwise not. (bool is routed to ULogicalNot.)
+  template <class T> static MD_HD T apply(T x) { return (T)~x; }
+};
+// bool-valued unaries
+struct ULogicalNot {
+  template <class T> static MD_HD b8 apply(T x) { return b8{(uint8_t)(x == (T)0)}; }
+};
+struct UIsnan {
+  template <class T> static MD_HD b8 apply(T x) { return b8{(uint8_t)md_isnan(x)}; }
+};
+
+// ============================ binary ==========================================
+template <class T> struct md_uint_of {
+  using type = typename std::conditional<sizeof(T) == 8, uint64_t,
+               typename std::conditional<sizeof(T) == 4, uint32_t, uint8_t>::type>::type;
+};
+struct BAdd {
+  template <class T> static MD_HD T apply(T a, T b) {
+    if constexpr (md_is_float<T>::value) return a + b;
+    else { using U = typename md_uint_of<T>::type; return (T)((U)a + (U)b); }
+  }
+};
+struct BSub {
+  template <class T> static MD_HD T apply(T a, T b) {
+    if constexpr (md_is_float<T>::value) return a - b;
+    else { using U = typename md_uint_of<T>::type; return (T)((U)a - (U)b); }
+  }
+};
+struct BMul {
+  template <class T> static MD_HD T apply(T a, T b) {
+    if constexpr (md_is_float<T>::value) return a * b;
+    else { using U = typename md_uint_of<T>::type; return (T)((U)a * (U)b); }
+  }
+};
+struct BTrueDiv {
+  template <class T> static MD_HD T apply(T a, T b) { return a / b; }
+};
+// NumPy npy_divmod (floats) / floor_div_@TYPE@ (ints): result takes the sign of
+// the divisor; integer x // 0 == 0 and x % 0 == 0.
+template <class T> MD_HD T md_float_divmod(T a, T b, T *modulus) {
+  T mod = md_fmod(a, b);
+  if (b == (T)0) {
+    *modulus = mod;
+    return a / b;
+  }
+  T div = (a - mod) / b;
+  if (mod != (T)0) {
+    if ((b < (T)0) != (mod < (T)0)) {
+      mod += b;
+      div -= (T)1;
+    }
+  } else {
+    mod = md_copysign((T)0, b);
+  }
+  T floordiv;
+  if (div != (T)0) {
+    floordiv = md_floor(div);
+    if (div - floordiv > (T)0.5) floordiv += (T)1;
+  } else {
+    floordiv = md_copysign((T)0, a / b);
+  }
+  *modulus = mod;
+  return floordiv;
+}
+struct BFloorDiv {
+  template <class T> static MD_HD T apply(T a, T b) {
+    if constexpr (md_is_float<T>::value) {
+      T m;
+      return md_float_divmod(a, b, &m);
+    } else {
+      if (b == 0) return 0;
+      if (b == (T)-1) { using U = typename md_uint_of<T>::type; return (T)((U)0 - (U)a); }
+      T q = a / b;
+      if (((a > 0) != (b > 0)) && (q * b != a)) q -= 1;
+      return q;
+    }
+  }
+};
+struct BMod {
+  template <class T> static MD_HD T apply(T a, T b) {
+    if constexpr (md_is_float<T>::value) {
+      T m;
+      md_float_divmod(a, b, &m);
+      return m;
+    } else {
+      if (b == 0) return 0;
+      if (b == (T)-1) return 0;
+      T r = a % b;
+      if (r != 0 && ((r < 0) != (b < 0))) r += b;
+      return r;
+    }
+  }
+};
+struct BPow {
+  template <class T> static MD_HD T apply(T a, T b) {
+    if constexpr (md_is_float<T>::value) {
+      // exact shortcuts for the exponents the tape produces (x**2, x**1, x**0.5)
+      if (b == (T)2) return a * a;
+      if (b == (T)1) return a;
+      if (b == (T)0) return (T)1;
+      if (b == (T)0.5 && a >= (T)0 && a == a && a != (T)INFINITY) return md_sqrt(a);
+      if (b == (T)-1) return (T)1 / a;
+      return md_pow(a, b);
+    } else {
+      // npy integer power: square-and-multiply, wraps; negative exponents are
+      // rejected before launch (ValueError in NumPy).
+      using U = typename md_uint_of<T>::type;
+      if (b == 0) return 1;
+      if (a == 1) return 1;
+      if (b < 0) return 0;
+      U base = (U)a, acc = 1;
+      U e = (U)b;
+      while (e) {
+        if (e & 1) acc *= base;
+        base *= base;
+        e >>= 1;
+      }
+      return (T)acc;
+    }
+  }
+};
+struct BMaximum {
+  template <class T> static MD_HD T apply(T a, T b) {
+    if constexpr (md_is_float<T>::value) return (a >= b || a != a) ? a : b;
+    else return a >= b ? a : b;
+  }
+};
+struct BMinimum {
+  template <class T> static MD_HD T apply(T a, T b) {
+    if constexpr (md_is_float<T>::value) return (a <= b || a != a) ? a : b;
+    else return a <= b ? a : b;
+  }
+};
+#define MD_BCMP(Name, expr)                                                           \
+  struct Name {                                                                       \
+    template <class T> static MD_HD b8 apply(T a, T b) { return b8{(uint8_t)(expr)}; } \
+  };
+MD_BCMP(BEq, a == b)
+MD_BCMP(BNe, a != b)
+MD_BCMP(BLt, a < b)
+MD_BCMP(BLe, a <= b)
+MD_BCMP(BGt, a > b)
+MD_BCMP(BGe, a >= b)
+// logical ops run on truth values (compute type uint8 holding 0/1)
+MD_BCMP(BLand, (a != (T)0) && (b != (T)0))
+MD_BCMP(BLor, (a != (T)0) || (b != (T)0))
+MD_BCMP(BLxor, (a != (T)0) != (b != (T)0))
+#undef MD_BCMP
+
+// ============================ reductions ======================================
+// combine(acc, x) must be associative up to fp rounding; identity<T>() seeds it.
+struct RSum {
+  template <class T> static MD_HD T identity() { return (T)0; }
+  template <class T> static MD_HD T combine(T a, T b) { return BAdd::apply(a, b); }
+};
+struct RProd {
+  template <class T> static MD_HD T identity() { return (T)1; }
+  template <class T> static MD_HD T combine(T a, T b) { return BMul::apply(a, b); }
+};
+template <class T> MD_HD T md_lowest() {
+  if constexpr (md_is_float<T>::value) return (T)-INFINITY;
+  else if constexpr (sizeof(T) == 8) return (T)INT64_MIN;
+  else if constexpr (sizeof(T) == 4) return (T)INT32_MIN;
+  else return (T)0;
+}
+template <class T> MD_HD T md_highest() {
+  if constexpr (md_is_float<T>::value) return (T)INFINITY;
+  else if constexpr (sizeof(T) == 8) return (T)INT64_MAX;
+  else if constexpr (sizeof(T) == 4) return (T)INT32_MAX;
+  else return (T)1;
+}
+struct RMax {  // NaN-propagating like np.max
+  template <class T> static MD_HD T identity() { return md_lowest<T>(); }
+  template <class T> static MD_HD T combine(T a, T b) {
+    if constexpr (md_is_float<T>::value) {
+      if (a != a) return a;
+      if (b != b) return b;
+    }
+    return a >= b ? a : b;
+  }
+};
+struct RMin {
+  template <class T> static MD_HD T identity() { return md_highest<T>(); }
+  template <class T> static MD_HD T combine(T a, T b) {
+    if constexpr (md_is_float<T>::value) {
+      if (a != a) return a;
+      if (b != b) return b;
+    }
+    return a <= b ? a : b;
+  }
+};
+struct RAny {  // on truth values
+  template <class T> static MD_HD T identity() { return (T)0; }
+  template <class T> static MD_HD T combine(T a, T b) { return (T)((a != (T)0) || (b != (T)0)); }
+};
+struct RAll {
+  template <class T> static MD_HD T identity() { return (T)1; }
+  template <class T> static MD_HD T combine(T a, T b) { return (T)((a != (T)0) && (b != (T)0)); }
+};
+
+// arg-reductions carry (value, position); first occurrence wins, NaN wins outright
+template <class T> struct md_argpair {
+  T v;
+  int64_t i;
+};
+template <bool IsMax> struct RArg {
+  template <class T> static MD_HD md_argpair<T> identity() {
+    return md_argpair<T>{IsMax ? md_lowest<T>() : md_highest<T>(), INT64_MAX};
+  }
+  template <class T> static MD_HD bool better(T a, T b) {  // a strictly better than b
+    if constexpr (md_is_float<T>::value) {
+      if (a != a) return !(b != b);
+      if (b != b) return false;
+    }
+    return IsMax ? (a > b) : (a < b);
+  }
+  template <class T> static MD_HD md_argpair<T> combine(md_argpair<T> a, md_argpair<T> b) {
+    if (b.i == INT64_MAX) return a;
+    if (a.i == INT64_MAX) return b;
+    if (better(a.v, b.v)) return a;
+    if (better(b.v, a.v)) return b;
+    return a.i <= b.i ? a : b;
+  }
+};

@@ -1,0 +1,278 @@
+// mdhip_host.cpp — CPU TEST DOUBLE of the libmdhip C-ABI (include/mdhip.h).
+//
+// TEST INFRASTRUCTURE ONLY. This file is not part of the product: the product
+// library is minidiff_amd/libmdhip.so (HIP, gfx950) and the package refuses to
+// load anything whose mdhip_target() is not "hip:gfx950" unless a test passes
+// the path explicitly. Only tests/ (and the developer, in this GPU-less
+// container) load this double, for two purposes:
+//   1. exercise the Python shim (views, NumPy promotion, descriptor building,
+//      index plans) against NumPy without a GPU, and
+//   2. plug the shim into the REAL reference (/root/reference, --backend flag,
+//      minidiff/backend/__init__.py:13-19,43-77) to prove the drop-in boundary.
+// It shares csrc/md_ops.h + md_dispatch.h with the device build, so dispatch
+// and per-element semantics are the same code; the loops below are the naive
+// sequential restatement (no tiling, no vectorisation, k-ordered accumulation).
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../minidiff_amd/csrc/md_dispatch.h"
+
+std::string &md_err_slot() {
+  static thread_local std::string s;
+  return s;
+}
+
+namespace {
+std::mutex g_mu;
+std::map<void *, size_t> g_live;
+int64_t g_in_use = 0, g_peak = 0, g_nalloc = 0;
+
+struct HostExec {
+  template <class F, class Tc, class To>
+  static int unary(const MdIter &it, const mdhip_array *x, const mdhip_array *out) {
+    Tc sx = x->is_scalar ? md_scalar_as<Tc>(x) : Tc();
+    To *o = (To *)out->data;
+    int64_t offs[MD_MAX_OPS];
+    for (int64_t i = 0; i < it.total; ++i) {
+      md_iter_offsets(it, i, offs);
+      Tc v = x->is_scalar ? sx : md_load<Tc>(x->data, x->dtype, offs[0]);
+      o[offs[1]] = md_to_out<To>(F::apply(v));
+    }
+    return MDHIP_OK;
+  }
+  template <class F, class Tc, class To>
+  static int binary(const MdIter &it, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out) {
+    Tc sa = a->is_scalar ? md_scalar_as<Tc>(a) : Tc();
+    Tc sb = b->is_scalar ? md_scalar_as<Tc>(b) : Tc();
+    To *o = (To *)out->data;
+    int64_t offs[MD_MAX_OPS];
+    for (int64_t i = 0; i < it.total; ++i) {
+      md_iter_offsets(it, i, offs);
+      Tc va = a->is_scalar ? sa : md_load<Tc>(a->data, a->dtype, offs[0]);
+      Tc vb = b->is_scalar ? sb : md_load<Tc>(b->data, b->dtype, offs[1]);
+      o[offs[2]] = md_to_out<To>(F::apply(va, vb));
+    }
+    return MDHIP_OK;
+  }
+  template <class T>
+  static int where(const MdIter &it, const mdhip_array *c, const mdhip_array *a, const mdhip_array *b,
+                   const mdhip_array *out) {
+    uint8_t sc = c->is_scalar ? md_scalar_as<uint8_t>(c) : 0;
+    T sa = a->is_scalar ? md_scalar_as<T>(a) : T();
+    T sb = b->is_scalar ? md_scalar_as<T>(b) : T();
+    T *o = (T *)out->data;
+    int64_t offs[MD_MAX_OPS];
+    for (int64_t i = 0; i < it.total; ++i) {
+      md_iter_offsets(it, i, offs);
+      uint8_t vc = c->is_scalar ? sc : md_load<uint8_t>(c->data, c->dtype, offs[0]);
+      T va = a->is_scalar ? sa : md_load<T>(a->data, a->dtype, offs[1]);
+      T vb = b->is_scalar ? sb : md_load<T>(b->data, b->dtype, offs[2]);
+      o[offs[3]] = vc ? va : vb;
+    }
+    return MDHIP_OK;
+  }
+  template <class R, class Tacc, class To>
+  static int reduce(const MdRedPlan &pl, const mdhip_array *x, const mdhip_array *out) {
+    To *o = (To *)out->data;
+    for (int64_t i = 0; i < pl.n_out; ++i) {
+      int64_t xo, oo;
+      md_red_kept_offsets(pl, i, &xo, &oo);
+      Tacc acc = R::template identity<Tacc>();
+      for (int64_t r = 0; r < pl.n_red; ++r)
+        acc = R::combine(acc, md_load<Tacc>(x->data, x->dtype, xo + md_red_offset(pl, r)));
+      o[oo] = md_cast<To>(acc);
+    }
+    return MDHIP_OK;
+  }
+  template <bool IsMax, class T>
+  static int argreduce(const MdRedPlan &pl, const mdhip_array *x, const mdhip_array *out) {
+    int64_t *o = (int64_t *)out->data;
+    for (int64_t i = 0; i < pl.n_out; ++i) {
+      int64_t xo, oo;
+      md_red_kept_offsets(pl, i, &xo, &oo);
+      md_argpair<T> acc = RArg<IsMax>::template identity<T>();
+      for (int64_t r = 0; r < pl.n_red; ++r) {
+        md_argpair<T> cur{md_load<T>(x->data, x->dtype, xo + md_red_offset(pl, r)), r};
+        acc = RArg<IsMax>::combine(acc, cur);
+      }
+      o[oo] = acc.i;
+    }
+    return MDHIP_OK;
+  }
+  template <class T> static int gemm(const MdGemm &g) {
+    const T *A = (const T *)g.a, *B = (const T *)g.b;
+    T *C = (T *)g.c;
+    for (int64_t bi = 0; bi < g.batch; ++bi)
+      for (int64_t m = 0; m < g.M; ++m)
+        for (int64_t n = 0; n < g.N; ++n) {
+          T acc = (T)0;
+          for (int64_t k = 0; k < g.K; ++k) {
+            T av = A[bi * g.a_bs + m * g.a_ms + k * g.a_ks];
+            T bv = B[bi * g.b_bs + k * g.b_ks + n * g.b_ns];
+            if constexpr (md_is_float<T>::value) acc = std::fma(av, bv, acc);
+            else acc = BAdd::apply(acc, BMul::apply(av, bv));
+          }
+          C[bi * g.c_bs + m * g.c_ms + n * g.c_ns] = acc;
+        }
+    return MDHIP_OK;
+  }
+};
+}  // namespace
+
+extern "C" {
+
+int mdhip_init(int) { return MDHIP_OK; }
+int mdhip_device(int *d) { *d = -1; return MDHIP_OK; }
+const char *mdhip_target(void) { return "host"; }
+const char *mdhip_last_error(void) { return md_err_slot().c_str(); }
+
+int mdhip_alloc(size_t nbytes, void **ptr_out) {
+  size_t n = nbytes ? nbytes : 1;
+  void *p = nullptr;
+  if (posix_memalign(&p, 256, (n + 255) / 256 * 256) != 0 || !p)
+    return md_fail(MDHIP_EMEMORY, "host alloc of %zu bytes failed", nbytes);
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_live[p] = n;
+  g_in_use += (int64_t)n;
+  if (g_in_use > g_peak) g_peak = g_in_use;
+  ++g_nalloc;
+  *ptr_out = p;
+  return MDHIP_OK;
+}
+int mdhip_free(void *p) {
+  if (!p) return MDHIP_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_live.find(p);
+  if (it == g_live.end()) return md_fail(MDHIP_EVALUE, "free of unknown pointer %p", p);
+  g_in_use -= (int64_t)it->second;
+  g_live.erase(it);
+  free(p);
+  return MDHIP_OK;
+}
+int mdhip_empty_cache(void) { return MDHIP_OK; }
+int mdhip_mem_stats(int64_t s[4]) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  s[0] = g_in_use; s[1] = 0; s[2] = g_peak; s[3] = g_nalloc;
+  return MDHIP_OK;
+}
+int mdhip_h2d(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return MDHIP_OK; }
+int mdhip_d2h(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return MDHIP_OK; }
+int mdhip_d2d(void *d, const void *s, size_t n) { if (n) memmove(d, s, n); return MDHIP_OK; }
+int mdhip_sync(void) { return MDHIP_OK; }
+
+struct HostEvent { std::chrono::steady_clock::time_point t; };
+int mdhip_event_create(void **ev) { *ev = new HostEvent(); return MDHIP_OK; }
+int mdhip_event_record(void *ev) { ((HostEvent *)ev)->t = std::chrono::steady_clock::now(); return MDHIP_OK; }
+int mdhip_event_elapsed_ms(void *a, void *b, float *ms) {
+  *ms = std::chrono::duration<float, std::milli>(((HostEvent *)b)->t - ((HostEvent *)a)->t).count();
+  return MDHIP_OK;
+}
+int mdhip_event_destroy(void *ev) { delete (HostEvent *)ev; return MDHIP_OK; }
+
+int mdhip_unary(int op, const mdhip_array *x, const mdhip_array *out) { return md_unary_dispatch<HostExec>(op, x, out); }
+int mdhip_binary(int op, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out, int cdt) {
+  return md_binary_dispatch<HostExec>(op, a, b, out, cdt);
+}
+int mdhip_where(const mdhip_array *c, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out) {
+  return md_where_dispatch<HostExec>(c, a, b, out);
+}
+int mdhip_fill(const mdhip_array *out, const mdhip_array *scalar) {
+  if (!scalar || !scalar->is_scalar) return md_fail(MDHIP_EVALUE, "fill: value must be a scalar descriptor");
+  return md_unary_dispatch<HostExec>(MDHIP_U_COPY, scalar, out);
+}
+int mdhip_arange(const mdhip_array *out, double start, double step) {
+  MD_TRY(md_check_array(out, "arange out"));
+  if (out->ndim != 1) return md_fail(MDHIP_EVALUE, "arange: out must be 1-D");
+  for (int64_t i = 0; i < out->shape[0]; ++i) {
+    int64_t o = i * out->strides[0];
+    switch (out->dtype) {
+      case MDHIP_I32: ((int32_t *)out->data)[o] = (int32_t)((int64_t)start + i * (int64_t)step); break;
+      case MDHIP_I64: ((int64_t *)out->data)[o] = (int64_t)start + i * (int64_t)step; break;
+      case MDHIP_F32: ((float *)out->data)[o] = (float)(start + (double)i * step); break;
+      case MDHIP_F64: ((double *)out->data)[o] = start + (double)i * step; break;
+      default: return md_fail(MDHIP_ETYPE, "arange: unsupported dtype");
+    }
+  }
+  return MDHIP_OK;
+}
+int mdhip_reduce(int op, const mdhip_array *x, const mdhip_array *out, uint32_t mask) {
+  return md_reduce_dispatch<HostExec>(op, x, out, mask);
+}
+int mdhip_matmul(const mdhip_array *a, const mdhip_array *b, const mdhip_array *c) {
+  return md_matmul_dispatch<HostExec>(a, b, c);
+}
+
+int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const mdhip_array *out) {
+  MD_TRY(md_check_plan(pl));
+  MD_TRY(md_check_array(out, "gather out"));
+  if (out->ndim != pl->ndim) return md_fail(MDHIP_EVALUE, "gather: out ndim mismatch");
+  size_t es = md_dtype_size(dtype);
+  int64_t n = md_plan_total(pl), pos[MDHIP_MAX_NDIM];
+  for (int64_t i = 0; i < n; ++i) {
+    bool oob = false;
+    int64_t off = md_plan_offset(*pl, i, pos, &oob);
+    if (oob) return md_fail(MDHIP_EINDEX, "index out of bounds");
+    int64_t oo = 0;
+    for (int d = 0; d < pl->ndim; ++d) oo += pos[d] * out->strides[d];
+    memcpy((char *)out->data + oo * es, (const char *)src + off * es, es);
+  }
+  return MDHIP_OK;
+}
+int mdhip_scatter(const mdhip_index_plan *pl, void *dst, int dtype, const mdhip_array *val, int mode) {
+  MD_TRY(md_check_plan(pl));
+  MD_TRY(md_check_array(val, "scatter val"));
+  if (!val->is_scalar && val->dtype != dtype) return md_fail(MDHIP_ETYPE, "scatter: value dtype must match destination");
+  size_t es = md_dtype_size(dtype);
+  int64_t n = md_plan_total(pl), pos[MDHIP_MAX_NDIM];
+  for (int64_t i = 0; i < n; ++i) {  // bounds first: NumPy raises before writing
+    bool oob = false;
+    md_plan_offset(*pl, i, pos, &oob);
+    if (oob) return md_fail(MDHIP_EINDEX, "index out of bounds");
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    bool oob = false;
+    int64_t off = md_plan_offset(*pl, i, pos, &oob);
+    int64_t vo = 0;
+    if (!val->is_scalar) for (int d = 0; d < pl->ndim; ++d) vo += pos[d] * val->strides[d];
+#define MD_SC(code, T)                                                                    \
+  case code: {                                                                            \
+    T v = val->is_scalar ? md_scalar_as<T>(val) : ((const T *)val->data)[vo];             \
+    T *d = (T *)dst + off;                                                                \
+    if (mode == MDHIP_SCATTER_ADD) *d = BAdd::apply(*d, v); else *d = v;                  \
+  } break;
+    switch (dtype) {
+      case MDHIP_BOOL: {
+        uint8_t v = val->is_scalar ? md_scalar_as<uint8_t>(val) : ((const uint8_t *)val->data)[vo];
+        uint8_t *d = (uint8_t *)dst + off;
+        if (mode == MDHIP_SCATTER_ADD) *d = (uint8_t)(*d || v); else *d = v;
+      } break;
+      MD_SC(MDHIP_I32, int32_t)
+      MD_SC(MDHIP_I64, int64_t)
+      MD_SC(MDHIP_F32, float)
+      MD_SC(MDHIP_F64, double)
+    }
+#undef MD_SC
+    (void)es;
+  }
+  return MDHIP_OK;
+}
+
+// data-parallel entry points: the double has no collective; world size 1 only.
+int mdhip_comm_get_unique_id(uint8_t uid[MDHIP_UID_BYTES]) { memset(uid, 0, MDHIP_UID_BYTES); return MDHIP_OK; }
+static int g_nranks = 0;
+int mdhip_comm_init(int nranks, int, const uint8_t *) {
+  if (nranks != 1) return md_fail(MDHIP_ERUNTIME, "host test double has no collective backend (nranks=%d)", nranks);
+  g_nranks = 1;
+  return MDHIP_OK;
+}
+int mdhip_comm_allreduce_sum(void *, size_t, int) {
+  if (g_nranks != 1) return md_fail(MDHIP_ERUNTIME, "communicator not initialised");
+  return MDHIP_OK;
+}
+int mdhip_comm_destroy(void) { g_nranks = 0; return MDHIP_OK; }
+
+}  // extern "C"
