@@ -1,0 +1,339 @@
+// elementwise.hip — unary / binary / where / fill / arange kernels for gfx950.
+//
+// Serves the backend names of reference minidiff/backend/numpy.py:19-95 (unary
+// table, binary table, clip/where) and the creation family :98-103,125. All of
+// them are HBM-bound: one pass, every input byte read once,
+// every output byte written once.
+//
+// Two kernel families per arity:
+//  * fast  — output contiguous, iteration space collapsed to (rows, inner) with
+//            every operand's inner stride 0 or 1 (contiguous, row-broadcast such
+//            as the bias add, column-broadcast, stride-0 views of a 0-d seed, or a
+//            host scalar). 4 elements per lane: 16-B loads/stores for f32/i32,
+//            2x16 B for f64/i64, 4 B for bool masks; grid capped at 8 blocks/CU
+//            and strided, so each wave keeps several KiB in flight.
+//  * generic — any strides (negative, permuted, up to 8-D) and any source dtype
+//            via a wave-uniform dtype switch; div/mod index walk.
+#include "md_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------ generic ----
+template <class F, class Tc, class To>
+__global__ void __launch_bounds__(MD_BLOCK) k_unary_generic(MdIter it, const void *x, int xdt, int x_scalar, Tc sx, To *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < it.total; i += stride) {
+    int64_t offs[MD_MAX_OPS];
+    md_iter_offsets(it, i, offs);
+    Tc v = x_scalar ? sx : md_load<Tc>(x, xdt, offs[0]);
+    out[offs[1]] = md_to_out<To>(F::apply(v));
+  }
+}
+
+template <class F, class Tc, class To>
+__global__ void __launch_bounds__(MD_BLOCK) k_binary_generic(MdIter it, const void *a, int adt, int a_scalar, Tc sa,
+                                                            const void *b, int bdt, int b_scalar, Tc sb, To *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < it.total; i += stride) {
+    int64_t offs[MD_MAX_OPS];
+    md_iter_offsets(it, i, offs);
+    Tc va = a_scalar ? sa : md_load<Tc>(a, adt, offs[0]);
+    Tc vb = b_scalar ? sb : md_load<Tc>(b, bdt, offs[1]);
+    out[offs[2]] = md_to_out<To>(F::apply(va, vb));
+  }
+}
+
+template <class T>
+__global__ void __launch_bounds__(MD_BLOCK) k_where_generic(MdIter it, const void *c, int cdt, int c_scalar, uint8_t sc,
+                                                           const void *a, int adt, int a_scalar, T sa,
+                                                           const void *b, int bdt, int b_scalar, T sb, T *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < it.total; i += stride) {
+    int64_t offs[MD_MAX_OPS];
+    md_iter_offsets(it, i, offs);
+    uint8_t vc = c_scalar ? sc : md_load<uint8_t>(c, cdt, offs[0]);
+    T va = a_scalar ? sa : md_load<T>(a, adt, offs[1]);
+    T vb = b_scalar ? sb : md_load<T>(b, bdt, offs[2]);
+    out[offs[3]] = vc ? va : vb;
+  }
+}
+
+// --------------------------------------------------------------------- fast ----
+template <class T> struct FastOp {
+  const T *p;   // nullptr -> host scalar
+  int64_t os;   // outer (row) stride, elements
+  int32_t is;   // inner stride: 0 or 1
+};
+
+template <class Tc> struct md_storage { using type = Tc; };
+template <> struct md_storage<uint8_t> { using type = b8; };
+
+template <class T, class Tc>
+__device__ __forceinline__ void md_fast_load(const FastOp<T> &o, Tc s, int64_t row, int64_t c, Tc (&r)[4]) {
+  if (o.p == nullptr) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = s;
+  } else if (o.is) {
+    MdVec<T, 4> v = *reinterpret_cast<const MdVec<T, 4> *>(o.p + row * o.os + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = md_cast<Tc>(v.v[j]);
+  } else {
+    Tc s1 = md_cast<Tc>(o.p[row * o.os]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = s1;
+  }
+}
+template <class T, class Tc>
+__device__ __forceinline__ Tc md_fast_load1(const FastOp<T> &o, Tc s, int64_t row, int64_t c) {
+  if (o.p == nullptr) return s;
+  return md_cast<Tc>(o.p[row * o.os + (o.is ? c : 0)]);
+}
+
+__device__ __forceinline__ void md_row_col(int64_t v, int64_t nv, int64_t rows, int64_t &row, int64_t &cv) {
+  if (rows == 1) {
+    row = 0;
+    cv = v;
+  } else if ((uint64_t)v < 0x100000000ull && (uint64_t)nv < 0x100000000ull) {
+    uint32_t q = (uint32_t)v / (uint32_t)nv;
+    row = q;
+    cv = (uint32_t)v - q * (uint32_t)nv;
+  } else {
+    row = v / nv;
+    cv = v - row * nv;
+  }
+}
+
+template <class F, class Tc, class To, class Tx>
+__global__ void __launch_bounds__(MD_BLOCK) k_unary_fast(FastOp<Tx> x, Tc sx, To *out, int64_t rows, int64_t inner) {
+  const int64_t nv = inner >> 2, total = rows * nv;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t v = gid; v < total; v += stride) {
+    int64_t row, cv;
+    md_row_col(v, nv, rows, row, cv);
+    const int64_t c = cv << 2;
+    Tc xv[4];
+    md_fast_load(x, sx, row, c, xv);
+    MdVec<To, 4> o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = md_to_out<To>(F::apply(xv[j]));
+    *reinterpret_cast<MdVec<To, 4> *>(out + row * inner + c) = o;
+  }
+  if (rows == 1) {
+    const int64_t t0 = nv << 2;
+    if (gid < inner - t0) out[t0 + gid] = md_to_out<To>(F::apply(md_fast_load1(x, sx, 0, t0 + gid)));
+  }
+}
+
+template <class F, class Tc, class To, class Ta, class Tb>
+__global__ void __launch_bounds__(MD_BLOCK) k_binary_fast(FastOp<Ta> a, FastOp<Tb> b, Tc sa, Tc sb, To *out, int64_t rows, int64_t inner) {
+  const int64_t nv = inner >> 2, total = rows * nv;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t v = gid; v < total; v += stride) {
+    int64_t row, cv;
+    md_row_col(v, nv, rows, row, cv);
+    const int64_t c = cv << 2;
+    Tc xv[4], yv[4];
+    md_fast_load(a, sa, row, c, xv);
+    md_fast_load(b, sb, row, c, yv);
+    MdVec<To, 4> o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = md_to_out<To>(F::apply(xv[j], yv[j]));
+    *reinterpret_cast<MdVec<To, 4> *>(out + row * inner + c) = o;
+  }
+  if (rows == 1) {
+    const int64_t t0 = nv << 2;
+    if (gid < inner - t0)
+      out[t0 + gid] = md_to_out<To>(F::apply(md_fast_load1(a, sa, 0, t0 + gid), md_fast_load1(b, sb, 0, t0 + gid)));
+  }
+}
+
+template <class T, class Tcnd>
+__global__ void __launch_bounds__(MD_BLOCK) k_where_fast(FastOp<Tcnd> c, FastOp<T> a, FastOp<T> b, uint8_t sc, T sa, T sb, T *out,
+                                                        int64_t rows, int64_t inner) {
+  const int64_t nv = inner >> 2, total = rows * nv;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t v = gid; v < total; v += stride) {
+    int64_t row, cv;
+    md_row_col(v, nv, rows, row, cv);
+    const int64_t col = cv << 2;
+    uint8_t cc[4];
+    T xv[4], yv[4];
+    md_fast_load(c, sc, row, col, cc);
+    md_fast_load(a, sa, row, col, xv);
+    md_fast_load(b, sb, row, col, yv);
+    MdVec<T, 4> o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = cc[j] ? xv[j] : yv[j];
+    *reinterpret_cast<MdVec<T, 4> *>(out + row * inner + col) = o;
+  }
+  if (rows == 1) {
+    const int64_t t0 = nv << 2;
+    if (gid < inner - t0) {
+      const int64_t i = t0 + gid;
+      out[i] = md_fast_load1(c, sc, 0, i) ? md_fast_load1(a, sa, 0, i) : md_fast_load1(b, sb, 0, i);
+    }
+  }
+}
+
+// ------------------------------------------------------- fast-path eligibility ----
+struct FastGeom {
+  int64_t rows, inner;
+};
+static bool fast_geom(const MdIter &it, int out_k, FastGeom *g) {
+  if (it.ndim == 1) {
+    if (it.strides[out_k][0] != 1) return false;
+    g->rows = 1;
+    g->inner = it.shape[0];
+    return true;
+  }
+  if (it.ndim == 2) {
+    if (it.strides[out_k][1] != 1 || it.strides[out_k][0] != it.shape[1]) return false;
+    if (it.shape[1] & 3) return false;
+    g->rows = it.shape[0];
+    g->inner = it.shape[1];
+    return true;
+  }
+  return false;
+}
+template <class T> static bool fast_aligned(const void *p) {
+  const uintptr_t al = sizeof(T) * 4 > 16 ? 16 : sizeof(T) * 4;
+  return ((uintptr_t)p % al) == 0;
+}
+template <class T> static bool fast_operand(const MdIter &it, int k, const mdhip_array *arr, const FastGeom &g, FastOp<T> *f) {
+  if (arr->is_scalar) {
+    f->p = nullptr; f->os = 0; f->is = 0;
+    return true;
+  }
+  if (arr->dtype != md_dtype_of<T>::value) return false;
+  const int64_t is = it.strides[k][it.ndim - 1];
+  const int64_t os = it.ndim == 2 ? it.strides[k][0] : 0;
+  if (is != 0 && is != 1) return false;
+  if (is == 1) {
+    if (!fast_aligned<T>(arr->data)) return false;
+    if (g.rows > 1 && (os & 3)) return false;
+  }
+  f->p = (const T *)arr->data;
+  f->os = os;
+  f->is = (int32_t)is;
+  return true;
+}
+
+struct HipExec {
+  // ------------------------------------------------------------------ unary ----
+  template <class F, class Tc, class To>
+  static int unary(const MdIter &it, const mdhip_array *x, const mdhip_array *out) {
+    using Tx = typename md_storage<Tc>::type;
+    hipStream_t st = md_stream();
+    Tc sx = x->is_scalar ? md_scalar_as<Tc>(x) : Tc();
+    FastGeom g;
+    FastOp<Tx> fx;
+    if (fast_geom(it, 1, &g) && fast_aligned<To>(out->data) && fast_operand<Tx>(it, 0, x, g, &fx)) {
+      const int64_t work = g.rows * (g.inner >> 2) + (g.rows == 1 ? 4 : 0);
+      k_unary_fast<F, Tc, To, Tx><<<md_grid_for(work), MD_BLOCK, 0, st>>>(fx, sx, (To *)out->data, g.rows, g.inner);
+      return MD_LAUNCH_CHECK("unary(fast)");
+    }
+    k_unary_generic<F, Tc, To><<<md_grid_for(it.total), MD_BLOCK, 0, st>>>(it, x->data, x->dtype, x->is_scalar, sx, (To *)out->data);
+    return MD_LAUNCH_CHECK("unary(generic)");
+  }
+
+  // ----------------------------------------------------------------- binary ----
+  template <class F, class Tc, class To, class Ta, class Tb>
+  static bool try_binary_fast(const MdIter &it, const FastGeom &g, const mdhip_array *a, const mdhip_array *b,
+                              const mdhip_array *out, Tc sa, Tc sb, int *status) {
+    FastOp<Ta> fa;
+    FastOp<Tb> fb;
+    if (!fast_operand<Ta>(it, 0, a, g, &fa) || !fast_operand<Tb>(it, 1, b, g, &fb)) return false;
+    const int64_t work = g.rows * (g.inner >> 2) + (g.rows == 1 ? 4 : 0);
+    k_binary_fast<F, Tc, To, Ta, Tb><<<md_grid_for(work), MD_BLOCK, 0, md_stream()>>>(fa, fb, sa, sb, (To *)out->data, g.rows, g.inner);
+    *status = MD_LAUNCH_CHECK("binary(fast)");
+    return true;
+  }
+  template <class F, class Tc, class To>
+  static int binary(const MdIter &it, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out) {
+    using Ts = typename md_storage<Tc>::type;
+    Tc sa = a->is_scalar ? md_scalar_as<Tc>(a) : Tc();
+    Tc sb = b->is_scalar ? md_scalar_as<Tc>(b) : Tc();
+    FastGeom g;
+    if (!(a->is_scalar && b->is_scalar) && fast_geom(it, 2, &g) && fast_aligned<To>(out->data)) {
+      int status = MDHIP_OK;
+      if (try_binary_fast<F, Tc, To, Ts, Ts>(it, g, a, b, out, sa, sb, &status)) return status;
+      // bool mask times float payload (relu / where gradients: definitions.py:555-559)
+      if constexpr (std::is_same<F, BMul>::value && md_is_float<Tc>::value) {
+        if (try_binary_fast<F, Tc, To, Ts, b8>(it, g, a, b, out, sa, sb, &status)) return status;
+        if (try_binary_fast<F, Tc, To, b8, Ts>(it, g, a, b, out, sa, sb, &status)) return status;
+      }
+    }
+    k_binary_generic<F, Tc, To><<<md_grid_for(it.total), MD_BLOCK, 0, md_stream()>>>(
+        it, a->data, a->dtype, a->is_scalar, sa, b->data, b->dtype, b->is_scalar, sb, (To *)out->data);
+    return MD_LAUNCH_CHECK("binary(generic)");
+  }
+
+  // ------------------------------------------------------------------ where ----
+  template <class T>
+  static int where(const MdIter &it, const mdhip_array *c, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out) {
+    uint8_t sc = c->is_scalar ? md_scalar_as<uint8_t>(c) : 0;
+    T sa = a->is_scalar ? md_scalar_as<T>(a) : T();
+    T sb = b->is_scalar ? md_scalar_as<T>(b) : T();
+    FastGeom g;
+    FastOp<b8> fc;
+    FastOp<T> fa, fb;
+    if (fast_geom(it, 3, &g) && fast_aligned<T>(out->data) && fast_operand<b8>(it, 0, c, g, &fc) &&
+        fast_operand<T>(it, 1, a, g, &fa) && fast_operand<T>(it, 2, b, g, &fb)) {
+      const int64_t work = g.rows * (g.inner >> 2) + (g.rows == 1 ? 4 : 0);
+      k_where_fast<T, b8><<<md_grid_for(work), MD_BLOCK, 0, md_stream()>>>(fc, fa, fb, sc, sa, sb, (T *)out->data, g.rows, g.inner);
+      return MD_LAUNCH_CHECK("where(fast)");
+    }
+    k_where_generic<T><<<md_grid_for(it.total), MD_BLOCK, 0, md_stream()>>>(
+        it, c->data, c->dtype, c->is_scalar, sc, a->data, a->dtype, a->is_scalar, sa, b->data, b->dtype, b->is_scalar, sb,
+        (T *)out->data);
+    return MD_LAUNCH_CHECK("where(generic)");
+  }
+};
+
+template <class T> __global__ void __launch_bounds__(MD_BLOCK) k_arange(T *out, int64_t n, int64_t stride, double start, double step) {
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gs) {
+    if constexpr (md_is_float<T>::value) out[i * stride] = (T)(start + (double)i * step);
+    else out[i * stride] = (T)((int64_t)start + i * (int64_t)step);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdhip_unary(int op, const mdhip_array *x, const mdhip_array *out) { return md_unary_dispatch<HipExec>(op, x, out); }
+
+int mdhip_binary(int op, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out, int cdt) {
+  return md_binary_dispatch<HipExec>(op, a, b, out, cdt);
+}
+
+int mdhip_where(const mdhip_array *c, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out) {
+  return md_where_dispatch<HipExec>(c, a, b, out);
+}
+
+int mdhip_fill(const mdhip_array *out, const mdhip_array *scalar) {
+  if (!scalar || !scalar->is_scalar) return md_fail(MDHIP_EVALUE, "fill: value must be a scalar descriptor");
+  return md_unary_dispatch<HipExec>(MDHIP_U_COPY, scalar, out);
+}
+
+int mdhip_arange(const mdhip_array *out, double start, double step) {
+  MD_TRY(md_check_array(out, "arange out"));
+  if (out->ndim != 1) return md_fail(MDHIP_EVALUE, "arange: out must be 1-D");
+  const int64_t n = out->shape[0];
+  if (n == 0) return MDHIP_OK;
+  const int grid = md_grid_for(n);
+  switch (out->dtype) {
+    case MDHIP_I32: k_arange<int32_t><<<grid, MD_BLOCK, 0, md_stream()>>>((int32_t *)out->data, n, out->strides[0], start, step); break;
+    case MDHIP_I64: k_arange<int64_t><<<grid, MD_BLOCK, 0, md_stream()>>>((int64_t *)out->data, n, out->strides[0], start, step); break;
+    case MDHIP_F32: k_arange<float><<<grid, MD_BLOCK, 0, md_stream()>>>((float *)out->data, n, out->strides[0], start, step); break;
+    case MDHIP_F64: k_arange<double><<<grid, MD_BLOCK, 0, md_stream()>>>((double *)out->data, n, out->strides[0], start, step); break;
+    default: return md_fail(MDHIP_ETYPE, "arange: unsupported dtype %s", md_dtype_name(out->dtype));
+  }
+  return MD_LAUNCH_CHECK("arange");
+}
+
+}  // extern "C"

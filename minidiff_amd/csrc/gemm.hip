@@ -1,0 +1,229 @@
+// gemm.hip — matmul forward/backward on gfx950 matrix cores.
+//
+// Serves reference minidiff/backend/numpy.py:84 (np.matmul; also dot/tensordot
+// :68,91 through the shim) and with it the three GEMMs of
+// minidiff/ops/definitions.py:487-492:  C = A·B (NN), dA = G·Bᵀ (NT),
+// dB = Aᵀ·G (TN). The transposes arrive as strided VIEWS (x.T is a stride
+// permutation), so the kernel takes element strides for both operands and picks
+// a tile loader per layout instead of materialising a transpose.
+//
+// f32: v_mfma_f32_32x32x2_f32 — exact f32 fma chain in k order, 256 FLOP/clk/CU
+// (MI355X_MICROARCH.md "Matrix cores"): bound = 157.3 TFLOP/s.
+//   block tile 128x128x16, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles
+//   (64 accumulator VGPRs). Operands are staged in LDS k-major ([k][m], [k][n])
+//   so a fragment read is one conflict-free ds_read_b32 per MFMA operand; the
+//   LDS image is double-buffered and the next tile's global loads are issued
+//   before the current tile's 32 MFMAs, one barrier per k-step.
+//   Workgroup ids are remapped so the 8 XCDs each own a contiguous band of
+//   output tiles (per-XCD L2 locality on the shared A row panel).
+// other dtypes / ragged or unaligned shapes: guarded edge variant of the same
+// kernel (f32) or a plain LDS-tiled kernel (f64 / ints; test-sized problems).
+#include "md_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 16, LDP = 4;  // LDP: row pad (floats)
+
+struct GemmArgs {
+  const float *A, *B;
+  float *C;
+  int64_t M, N, K;
+  int64_t a_bs, a_ms, a_ks, b_bs, b_ks, b_ns, c_bs, c_ms, c_ns;
+  int tiles_m, tiles_n;
+};
+
+// Tile loaders. KC = the operand's k axis is the contiguous one in memory.
+// Each thread moves 2 x 16 B per operand per k-step.
+template <bool KC, bool EDGE>
+__device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t rs, int64_t ks, int64_t row0, int64_t k0,
+                                          int64_t rows, int64_t K, f32x4 (&r)[2]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row, k;
+    if constexpr (KC) { row = (t >> 2) + 64 * i; k = (t & 3) * 4; }
+    else { k = (t >> 5) + 8 * i; row = (t & 31) * 4; }
+    if constexpr (!EDGE) {
+      r[i] = *reinterpret_cast<const f32x4 *>(P + (row0 + row) * rs + (k0 + k) * ks);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t rr = row0 + row + (KC ? 0 : j), kk = k0 + k + (KC ? j : 0);
+        r[i][j] = (rr < rows && kk < K) ? P[rr * rs + kk * ks] : 0.0f;
+      }
+    }
+  }
+}
+template <bool KC>
+__device__ __forceinline__ void store_tile(float (*S)[BM + LDP], const f32x4 (&r)[2]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if constexpr (KC) {
+      const int row = (t >> 2) + 64 * i, k = (t & 3) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) S[k + j][row] = r[i][j];
+    } else {
+      const int k = (t >> 5) + 8 * i, row = (t & 31) * 4;
+      *reinterpret_cast<f32x4 *>(&S[k][row]) = r[i];
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC, bool EDGE>
+__global__ void __launch_bounds__(256) k_gemm_f32_mfma(GemmArgs g) {
+  __shared__ float As[2][BK][BM + LDP];
+  __shared__ float Bs[2][BK][BN + LDP];
+
+  // XCD-aware tile order: ids b, b+8, b+16.. share an XCD -> give them neighbours
+  const int nblk = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t bz = blockIdx.z;
+  const float *A = g.A + bz * g.a_bs;
+  const float *B = g.B + bz * g.b_bs;
+  float *C = g.C + bz * g.c_bs;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l32 = lane & 31, h = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  f32x4 ra[2], rb[2];
+  const int64_t nk = (g.K + BK - 1) / BK;
+  // A tile rows = m (row stride a_ms), B tile rows = n (row stride b_ns)
+  load_tile<A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, 0, g.M, g.K, ra);
+  load_tile<B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, 0, g.N, g.K, rb);
+  store_tile<A_KC>(As[0], ra);
+  store_tile<B_KC>(Bs[0], rb);
+  __syncthreads();
+
+  int cur = 0;
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      load_tile<A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 1) * BK, g.M, g.K, ra);
+      load_tile<B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 1) * BK, g.N, g.K, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[cur][kk + h][wm * 64 + i * 32 + l32];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[cur][kk + h][wn * 64 + j * 32 + l32];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      store_tile<A_KC>(As[cur ^ 1], ra);
+      store_tile<B_KC>(Bs[cur ^ 1], rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // C/D layout of the 32x32 accumulator: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = n0 + wn * 64 + j * 32 + l32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (!EDGE || (row < g.M && col < g.N)) C[row * g.c_ms + col * g.c_ns] = acc[i][j][r];
+      }
+    }
+}
+
+// ---- plain tiled kernel: any dtype, any strides (f64 / ints / tiny problems) ------
+template <class T>
+__global__ void __launch_bounds__(256) k_gemm_generic(MdGemm g) {
+  __shared__ T As[16][17];
+  __shared__ T Bs[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int64_t bz = blockIdx.z;
+  const T *A = (const T *)g.a + bz * g.a_bs;
+  const T *B = (const T *)g.b + bz * g.b_bs;
+  T *C = (T *)g.c + bz * g.c_bs;
+  const int64_t row = (int64_t)blockIdx.y * 16 + ty, col = (int64_t)blockIdx.x * 16 + tx;
+  T acc = (T)0;
+  for (int64_t k0 = 0; k0 < g.K; k0 += 16) {
+    const int64_t ka = k0 + tx, kb = k0 + ty;
+    As[ty][tx] = (row < g.M && ka < g.K) ? A[row * g.a_ms + ka * g.a_ks] : (T)0;
+    Bs[ty][tx] = (kb < g.K && col < g.N) ? B[kb * g.b_ks + col * g.b_ns] : (T)0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if constexpr (md_is_float<T>::value) acc = fma(As[ty][k], Bs[k][tx], acc);
+      else acc = BAdd::apply(acc, BMul::apply(As[ty][k], Bs[k][tx]));
+    }
+    __syncthreads();
+  }
+  if (row < g.M && col < g.N) C[row * g.c_ms + col * g.c_ns] = acc;
+}
+
+template <bool A_KC, bool B_KC>
+static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
+  dim3 grid((unsigned)(ga.tiles_m * ga.tiles_n), 1, (unsigned)batch);
+  if (edge) k_gemm_f32_mfma<A_KC, B_KC, true><<<grid, 256, 0, md_stream()>>>(ga);
+  else k_gemm_f32_mfma<A_KC, B_KC, false><<<grid, 256, 0, md_stream()>>>(ga);
+  return MD_LAUNCH_CHECK("matmul(f32 mfma)");
+}
+
+struct HipExec {
+  template <class T> static int gemm(const MdGemm &g) {
+    if (g.batch > 65535) return md_fail(MDHIP_EVALUE, "matmul: batch extent %lld exceeds 65535", (long long)g.batch);
+    if constexpr (std::is_same<T, float>::value) {
+      // each operand must have a unit stride along k or along its other axis
+      const bool a_kc = g.a_ks == 1 || g.K == 1, a_mc = g.a_ms == 1 || g.M == 1;
+      const bool b_kc = g.b_ks == 1 || g.K == 1, b_nc = g.b_ns == 1 || g.N == 1;
+      const bool big = g.M * g.N >= 64 * 64 && g.K >= 8;
+      if (big && (a_kc || a_mc) && (b_kc || b_nc) && g.M * g.N < (1ll << 40)) {
+        GemmArgs ga;
+        ga.A = (const float *)g.a; ga.B = (const float *)g.b; ga.C = (float *)g.c;
+        ga.M = g.M; ga.N = g.N; ga.K = g.K;
+        ga.a_bs = g.a_bs; ga.a_ms = g.a_ms; ga.a_ks = g.a_ks;
+        ga.b_bs = g.b_bs; ga.b_ks = g.b_ks; ga.b_ns = g.b_ns;
+        ga.c_bs = g.c_bs; ga.c_ms = g.c_ms; ga.c_ns = g.c_ns;
+        ga.tiles_m = (int)((g.M + BM - 1) / BM);
+        ga.tiles_n = (int)((g.N + BN - 1) / BN);
+        // prefer the layout that allows 16-B loads; A_KC means "vectorise A along k"
+        const bool A_KC = a_kc && !(a_mc && g.a_ks != 1), B_KC = b_kc && !(b_nc && g.b_ks != 1);
+        auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+        bool edge = (g.M % BM) || (g.N % BN) || (g.K % BK) || !al16(g.a) || !al16(g.b);
+        // the vector axis' partner stride must keep rows 16-B aligned
+        edge = edge || ((A_KC ? g.a_ms : g.a_ks) & 3) || ((B_KC ? g.b_ns : g.b_ks) & 3) || (g.a_bs & 3) || (g.b_bs & 3);
+        if (A_KC && B_KC) return launch_mfma<true, true>(ga, g.batch, edge);
+        if (A_KC && !B_KC) return launch_mfma<true, false>(ga, g.batch, edge);
+        if (!A_KC && B_KC) return launch_mfma<false, true>(ga, g.batch, edge);
+        return launch_mfma<false, false>(ga, g.batch, edge);
+      }
+    }
+    dim3 grid((unsigned)((g.N + 15) / 16), (unsigned)((g.M + 15) / 16), (unsigned)g.batch);
+    if (grid.y > 65535) return md_fail(MDHIP_EVALUE, "matmul: M too large for the generic kernel");
+    k_gemm_generic<T><<<grid, 256, 0, md_stream()>>>(g);
+    return MD_LAUNCH_CHECK("matmul(generic)");
+  }
+};
+
+}  // namespace
+
+extern "C" int mdhip_matmul(const mdhip_array *a, const mdhip_array *b, const mdhip_array *c) {
+  return md_matmul_dispatch<HipExec>(a, b, c);
+}

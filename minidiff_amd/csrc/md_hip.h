@@ -1,0 +1,44 @@
+// md_hip.h — device-side helpers shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "md_dispatch.h"
+
+hipStream_t md_stream();
+int md_hip_check(hipError_t e, const char *what);
+
+#define MD_LAUNCH_CHECK(name) md_hip_check(hipGetLastError(), name)
+
+// MI355X: 256 CUs. Streaming kernels cap the grid and stride (guide §6 G11).
+constexpr int MD_NUM_CUS = 256;
+constexpr int MD_BLOCK = 256;
+static inline int md_grid_for(int64_t work_items, int per_block = MD_BLOCK, int max_blocks = MD_NUM_CUS * 8) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+template <class T, int N> struct alignas(sizeof(T) * N > 16 ? 16 : sizeof(T) * N) MdVec {
+  T v[N];
+};
+
+// ---- wave / block reductions (wave = 64 lanes) ----------------------------------
+template <class T> __device__ __forceinline__ T md_shfl_down(T v, int delta) {
+  if constexpr (sizeof(T) == 8) {
+    union { T t; int32_t w[2]; } u;
+    u.t = v;
+    u.w[0] = __shfl_down(u.w[0], delta, 64);
+    u.w[1] = __shfl_down(u.w[1], delta, 64);
+    return u.t;
+  } else if constexpr (sizeof(T) == 4) {
+    union { T t; int32_t w; } u;
+    u.t = v;
+    u.w = __shfl_down(u.w, delta, 64);
+    return u.t;
+  } else {
+    int32_t w = (int32_t)v;
+    w = __shfl_down(w, delta, 64);
+    return (T)w;
+  }
+}

@@ -1,0 +1,267 @@
+// runtime.hip — process state of libmdhip: device binding, the single stream all
+// work is ordered on, the caching allocator, events, and the RCCL communicator.
+//
+// Reference counterpart: none as code — the reference leans on NumPy's allocator
+// and Python refcounts (SURVEY.md §5 "Memory management"). Temporaries of the
+// eager tape are freed by Python GC one op after they are produced, so blocks
+// are recycled through size-binned free lists instead of hipMalloc/hipFree
+// (which would serialise the device every call). Freed blocks may be handed out
+// again immediately: every producer and consumer runs on the same stream.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "md_hip.h"
+
+std::string &md_err_slot() {
+  static thread_local std::string s;
+  return s;
+}
+
+namespace {
+struct State {
+  std::mutex mu;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  std::map<size_t, std::vector<void *>> free_lists;  // rounded size -> blocks
+  std::unordered_map<void *, size_t> live;           // ptr -> rounded size
+  int64_t in_use = 0, cached = 0, peak = 0, n_malloc = 0;
+};
+State &S() {
+  static State s;
+  return s;
+}
+
+size_t round_size(size_t n) {
+  if (n == 0) n = 1;
+  if (n <= (1u << 20)) return (n + 511) & ~size_t(511);
+  const size_t g = size_t(2) << 20;
+  return (n + g - 1) / g * g;
+}
+
+int release_cache_locked(State &s) {
+  for (auto &kv : s.free_lists)
+    for (void *p : kv.second) {
+      (void)hipFree(p);
+      s.cached -= (int64_t)kv.first;
+    }
+  s.free_lists.clear();
+  return MDHIP_OK;
+}
+}  // namespace
+
+hipStream_t md_stream() { return S().stream; }
+
+int md_hip_check(hipError_t e, const char *what) {
+  if (e == hipSuccess) return MDHIP_OK;
+  return md_fail(e == hipErrorOutOfMemory ? MDHIP_EMEMORY : MDHIP_ERUNTIME, "%s: %s", what, hipGetErrorString(e));
+}
+
+extern "C" {
+
+const char *mdhip_target(void) { return "hip:gfx950"; }
+const char *mdhip_last_error(void) { return md_err_slot().c_str(); }
+
+int mdhip_init(int device) {
+  State &s = S();
+  std::lock_guard<std::mutex> lk(s.mu);
+  if (s.device == device && s.stream) return MDHIP_OK;
+  if (s.stream) return md_fail(MDHIP_ERUNTIME, "already bound to device %d", s.device);
+  int n = 0;
+  MD_TRY(md_hip_check(hipGetDeviceCount(&n), "hipGetDeviceCount"));
+  if (n <= 0) return md_fail(MDHIP_ERUNTIME, "no HIP device visible (libmdhip has no CPU fallback)");
+  if (device < 0 || device >= n) return md_fail(MDHIP_EVALUE, "device %d out of range (%d visible)", device, n);
+  MD_TRY(md_hip_check(hipSetDevice(device), "hipSetDevice"));
+  hipDeviceProp_t prop;
+  MD_TRY(md_hip_check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties"));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return md_fail(MDHIP_ERUNTIME, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+  MD_TRY(md_hip_check(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate"));
+  s.device = device;
+  return MDHIP_OK;
+}
+
+int mdhip_device(int *out) {
+  *out = S().device;
+  return MDHIP_OK;
+}
+
+int mdhip_alloc(size_t nbytes, void **ptr_out) {
+  State &s = S();
+  if (!s.stream) return md_fail(MDHIP_ERUNTIME, "mdhip_init has not been called");
+  size_t r = round_size(nbytes);
+  std::lock_guard<std::mutex> lk(s.mu);
+  void *p = nullptr;
+  auto it = s.free_lists.find(r);
+  if (it != s.free_lists.end() && !it->second.empty()) {
+    p = it->second.back();
+    it->second.pop_back();
+    s.cached -= (int64_t)r;
+  } else {
+    hipError_t e = hipMalloc(&p, r);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(s.stream);
+      release_cache_locked(s);
+      e = hipMalloc(&p, r);
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return md_fail(MDHIP_EMEMORY, "Unable to allocate %zu bytes of device memory (%s)", nbytes, hipGetErrorString(e));
+    }
+    ++s.n_malloc;
+  }
+  s.live[p] = r;
+  s.in_use += (int64_t)r;
+  if (s.in_use > s.peak) s.peak = s.in_use;
+  *ptr_out = p;
+  return MDHIP_OK;
+}
+
+int mdhip_free(void *p) {
+  if (!p) return MDHIP_OK;
+  State &s = S();
+  std::lock_guard<std::mutex> lk(s.mu);
+  auto it = s.live.find(p);
+  if (it == s.live.end()) return md_fail(MDHIP_EVALUE, "free of unknown device pointer %p", p);
+  size_t r = it->second;
+  s.live.erase(it);
+  s.in_use -= (int64_t)r;
+  s.free_lists[r].push_back(p);
+  s.cached += (int64_t)r;
+  return MDHIP_OK;
+}
+
+int mdhip_empty_cache(void) {
+  State &s = S();
+  if (s.stream) MD_TRY(md_hip_check(hipStreamSynchronize(s.stream), "hipStreamSynchronize"));
+  std::lock_guard<std::mutex> lk(s.mu);
+  return release_cache_locked(s);
+}
+
+int mdhip_mem_stats(int64_t st[4]) {
+  State &s = S();
+  std::lock_guard<std::mutex> lk(s.mu);
+  st[0] = s.in_use; st[1] = s.cached; st[2] = s.peak; st[3] = s.n_malloc;
+  return MDHIP_OK;
+}
+
+int mdhip_h2d(void *dst, const void *src, size_t n) {
+  if (!n) return MDHIP_OK;
+  MD_TRY(md_hip_check(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, md_stream()), "hipMemcpyAsync(H2D)"));
+  // the caller's host buffer may be a temporary: do not return before it is consumed
+  return md_hip_check(hipStreamSynchronize(md_stream()), "hipStreamSynchronize");
+}
+int mdhip_d2h(void *dst, const void *src, size_t n) {
+  if (!n) return MDHIP_OK;
+  MD_TRY(md_hip_check(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, md_stream()), "hipMemcpyAsync(D2H)"));
+  return md_hip_check(hipStreamSynchronize(md_stream()), "hipStreamSynchronize");
+}
+int mdhip_d2d(void *dst, const void *src, size_t n) {
+  if (!n) return MDHIP_OK;
+  return md_hip_check(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, md_stream()), "hipMemcpyAsync(D2D)");
+}
+int mdhip_sync(void) {
+  if (!S().stream) return MDHIP_OK;
+  MD_TRY(md_hip_check(hipStreamSynchronize(md_stream()), "hipStreamSynchronize"));
+  return md_hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+}
+
+int mdhip_event_create(void **ev) {
+  hipEvent_t e;
+  MD_TRY(md_hip_check(hipEventCreate(&e), "hipEventCreate"));
+  *ev = (void *)e;
+  return MDHIP_OK;
+}
+int mdhip_event_record(void *ev) { return md_hip_check(hipEventRecord((hipEvent_t)ev, md_stream()), "hipEventRecord"); }
+int mdhip_event_elapsed_ms(void *a, void *b, float *ms) {
+  MD_TRY(md_hip_check(hipEventSynchronize((hipEvent_t)b), "hipEventSynchronize"));
+  return md_hip_check(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b), "hipEventElapsedTime");
+}
+int mdhip_event_destroy(void *ev) { return md_hip_check(hipEventDestroy((hipEvent_t)ev), "hipEventDestroy"); }
+
+// ============================ RCCL ==============================================
+// One communicator per process. librccl is opened lazily so single-GPU runs never
+// pay for it. Only the five entry points below are used; types are restated from
+// rccl.h's public ABI (ncclUniqueId = 128 opaque bytes, ncclComm_t = pointer).
+typedef struct { char internal[128]; } md_ncclUniqueId;
+typedef void *md_ncclComm_t;
+enum { MD_NCCL_INT32 = 2, MD_NCCL_INT64 = 4, MD_NCCL_FLOAT32 = 7, MD_NCCL_FLOAT64 = 8, MD_NCCL_SUM = 0 };
+static struct {
+  void *h = nullptr;
+  int (*GetUniqueId)(md_ncclUniqueId *) = nullptr;
+  int (*CommInitRank)(md_ncclComm_t *, int, md_ncclUniqueId, int) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, md_ncclComm_t, hipStream_t) = nullptr;
+  int (*CommDestroy)(md_ncclComm_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  md_ncclComm_t comm = nullptr;
+  int nranks = 0;
+} R;
+
+static int rccl_load() {
+  if (R.h) return MDHIP_OK;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : names) {
+    R.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (R.h) break;
+  }
+  if (!R.h) return md_fail(MDHIP_ERUNTIME, "cannot open librccl: %s", dlerror());
+  R.GetUniqueId = (decltype(R.GetUniqueId))dlsym(R.h, "ncclGetUniqueId");
+  R.CommInitRank = (decltype(R.CommInitRank))dlsym(R.h, "ncclCommInitRank");
+  R.AllReduce = (decltype(R.AllReduce))dlsym(R.h, "ncclAllReduce");
+  R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.h, "ncclCommDestroy");
+  R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.h, "ncclGetErrorString");
+  if (!R.GetUniqueId || !R.CommInitRank || !R.AllReduce || !R.CommDestroy)
+    return md_fail(MDHIP_ERUNTIME, "librccl is missing an expected symbol");
+  return MDHIP_OK;
+}
+static int rccl_check(int st, const char *what) {
+  if (st == 0) return MDHIP_OK;
+  return md_fail(MDHIP_ERUNTIME, "%s: %s", what, R.GetErrorString ? R.GetErrorString(st) : "RCCL error");
+}
+
+int mdhip_comm_get_unique_id(uint8_t uid[MDHIP_UID_BYTES]) {
+  MD_TRY(rccl_load());
+  md_ncclUniqueId id;
+  MD_TRY(rccl_check(R.GetUniqueId(&id), "ncclGetUniqueId"));
+  static_assert(sizeof(id) == MDHIP_UID_BYTES, "ncclUniqueId size");
+  memcpy(uid, &id, sizeof id);
+  return MDHIP_OK;
+}
+int mdhip_comm_init(int nranks, int rank, const uint8_t uid[MDHIP_UID_BYTES]) {
+  if (!S().stream) return md_fail(MDHIP_ERUNTIME, "mdhip_init has not been called");
+  if (R.comm) return md_fail(MDHIP_ERUNTIME, "communicator already initialised");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return md_fail(MDHIP_EVALUE, "bad rank %d of %d", rank, nranks);
+  MD_TRY(rccl_load());
+  md_ncclUniqueId id;
+  memcpy(&id, uid, sizeof id);
+  MD_TRY(rccl_check(R.CommInitRank(&R.comm, nranks, id, rank), "ncclCommInitRank"));
+  R.nranks = nranks;
+  return MDHIP_OK;
+}
+int mdhip_comm_allreduce_sum(void *buf, size_t count, int dtype) {
+  if (!R.comm) return md_fail(MDHIP_ERUNTIME, "communicator not initialised");
+  int nt;
+  switch (dtype) {
+    case MDHIP_I32: nt = MD_NCCL_INT32; break;
+    case MDHIP_I64: nt = MD_NCCL_INT64; break;
+    case MDHIP_F32: nt = MD_NCCL_FLOAT32; break;
+    case MDHIP_F64: nt = MD_NCCL_FLOAT64; break;
+    default: return md_fail(MDHIP_ETYPE, "allreduce: unsupported dtype %s", md_dtype_name(dtype));
+  }
+  return rccl_check(R.AllReduce(buf, buf, count, nt, MD_NCCL_SUM, R.comm, md_stream()), "ncclAllReduce");
+}
+int mdhip_comm_destroy(void) {
+  if (!R.comm) return MDHIP_OK;
+  (void)hipStreamSynchronize(md_stream());
+  int st = R.CommDestroy(R.comm);
+  R.comm = nullptr;
+  R.nranks = 0;
+  return rccl_check(st, "ncclCommDestroy");
+}
+
+}  // extern "C"

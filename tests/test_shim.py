@@ -1,0 +1,71 @@
+"""Shim (DeviceArray + NumPy-semantics layer over the C-ABI) vs NumPy.
+
+The same cases run twice: on the CPU test double here (`-m "not gpu"`, proves
+the host logic) and on the HIP library on a real MI355X (`-m gpu`, the parity
+tests proper — every call goes through libmdhip.so)."""
+import numpy as np
+import pytest
+
+import cases_shim as cs
+
+FLOATS = [np.float32, np.float64]
+NUMS = [np.float32, np.float64, np.int64, np.int32]
+MIXED = ["add", "multiply", "true_divide", "less", "power", "maximum", "logical_or"]
+RDT = [np.float32, np.float64, np.int64]
+MDT = [np.float32, np.float64, np.int64]
+gpu = pytest.mark.gpu
+
+
+def _run(lib, on_gpu, want_gpu, fn, *args):
+    from minidiff_amd import ndarray
+    if want_gpu:
+        assert on_gpu and lib.target == "hip:gfx950"
+    elif on_gpu:
+        pytest.skip("GPU present: covered by the gpu-marked twin")
+    fn(ndarray, *args)
+
+
+@pytest.mark.parametrize("dtype", NUMS)
+@pytest.mark.parametrize("name", cs.BINARY)
+def test_binary_cpu(lib, on_gpu, name, dtype): _run(lib, on_gpu, False, cs.case_binary, name, dtype)
+@gpu
+@pytest.mark.parametrize("dtype", NUMS)
+@pytest.mark.parametrize("name", cs.BINARY)
+def test_binary_gpu(lib, on_gpu, name, dtype): _run(lib, on_gpu, True, cs.case_binary, name, dtype)
+
+@pytest.mark.parametrize("name", MIXED)
+def test_binary_mixed_cpu(lib, on_gpu, name): _run(lib, on_gpu, False, cs.case_binary_mixed, name)
+@gpu
+@pytest.mark.parametrize("name", MIXED)
+def test_binary_mixed_gpu(lib, on_gpu, name): _run(lib, on_gpu, True, cs.case_binary_mixed, name)
+
+@pytest.mark.parametrize("dtype", FLOATS)
+@pytest.mark.parametrize("name", cs.UNARY_F)
+def test_unary_cpu(lib, on_gpu, name, dtype): _run(lib, on_gpu, False, cs.case_unary, name, dtype)
+@gpu
+@pytest.mark.parametrize("dtype", FLOATS)
+@pytest.mark.parametrize("name", cs.UNARY_F)
+def test_unary_gpu(lib, on_gpu, name, dtype): _run(lib, on_gpu, True, cs.case_unary, name, dtype)
+
+@pytest.mark.parametrize("dtype", RDT)
+@pytest.mark.parametrize("name", cs.REDUCE)
+def test_reduce_cpu(lib, on_gpu, name, dtype): _run(lib, on_gpu, False, cs.case_reduce, name, dtype)
+@gpu
+@pytest.mark.parametrize("dtype", RDT)
+@pytest.mark.parametrize("name", cs.REDUCE)
+def test_reduce_gpu(lib, on_gpu, name, dtype): _run(lib, on_gpu, True, cs.case_reduce, name, dtype)
+
+@pytest.mark.parametrize("dtype", MDT)
+def test_matmul_cpu(lib, on_gpu, dtype): _run(lib, on_gpu, False, cs.case_matmul, dtype)
+@gpu
+@pytest.mark.parametrize("dtype", MDT)
+def test_matmul_gpu(lib, on_gpu, dtype): _run(lib, on_gpu, True, cs.case_matmul, dtype)
+
+SINGLE = ["case_unary_int", "case_reduce_large", "case_argreduce", "case_layout", "case_matmul_mfma", "case_where_clip",
+          "case_indexing", "case_inplace", "case_errors"]
+
+@pytest.mark.parametrize("case", SINGLE)
+def test_case_cpu(lib, on_gpu, case): _run(lib, on_gpu, False, getattr(cs, case))
+@gpu
+@pytest.mark.parametrize("case", SINGLE)
+def test_case_gpu(lib, on_gpu, case): _run(lib, on_gpu, True, getattr(cs, case))
