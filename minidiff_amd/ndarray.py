@@ -154,7 +154,7 @@ class DeviceArray:
     def from_numpy(arr) -> "DeviceArray":
         arr = np.asarray(arr)
         dtype_code(arr.dtype)
-        host = np.ascontiguousarray(arr)
+        host = arr if arr.flags.c_contiguous else np.array(arr, order="C")  # (ascontiguousarray would promote 0-d to 1-d)
         out = DeviceArray.empty(host.shape, host.dtype)
         if host.nbytes:
             _lib().h2d(out.ptr, host.ctypes.data, host.nbytes)
