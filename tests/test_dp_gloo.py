@@ -1,0 +1,66 @@
+"""N>1 path on CPU: two processes, gloo, the sharded sweep + gradient all-reduce
+(SURVEY.md §8e). The RCCL communicator itself is covered on the GPU box with a
+single-rank communicator (test_rccl_single_rank_gpu)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_dp_world2_gloo():
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=300)
+            outs.append(out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
+        assert f"DP-OK rank {rank}/2" in out
+
+
+def test_shard_rows():
+    from minidiff_amd import dp
+    assert dp.shard_rows(8192, 3, 8) == slice(3072, 4096)
+    with pytest.raises(ValueError):
+        dp.shard_rows(10, 0, 4)
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_gpu(lib, on_gpu):
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllReduce through the C-ABI on the
+    library's stream, world size 1 (the only size a one-GPU box allows)."""
+    assert on_gpu
+    from minidiff_amd import dp, ndarray as nd
+    comm = dp.RcclComm(0, 1)
+    x = np.random.default_rng(0).standard_normal(1 << 20).astype(np.float32)
+    d = nd.asarray(x)
+    comm.allreduce_sum_(d)
+    assert np.array_equal(d.get(), x)
+    di = nd.asarray(np.arange(1000))
+    comm.allreduce_sum_(di)
+    assert np.array_equal(di.get(), np.arange(1000))
+    comm.close()
