@@ -9,8 +9,9 @@
 //
 // f32: v_mfma_f32_32x32x2_f32 — exact f32 fma chain in k order, 256 FLOP/clk/CU
 // (MI355X_MICROARCH.md "Matrix cores"): bound = 157.3 TFLOP/s.
-//   block tile 128x128x16, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles
-//   (64 accumulator VGPRs). Operands are staged in LDS k-major ([k][m], [k][n])
+//   block tile BM x BN x BK (128x128x16 by default; smaller tiles when the problem
+//   would otherwise leave CUs with <3 resident blocks), 4 waves (2x2), each wave
+//   (BM/2)x(BN/2) in 32x32 MFMA tiles (64 accumulator VGPRs at 128x128). Operands are staged in LDS k-major ([k][m], [k][n])
 //   so a fragment read is one conflict-free ds_read_b32 per MFMA operand; the
 //   LDS image is double-buffered and the next tile's global loads are issued
 //   before the current tile's 32 MFMAs, one barrier per k-step.
@@ -18,6 +19,8 @@
 //   output tiles (per-XCD L2 locality on the shared A row panel).
 // other dtypes / ragged or unaligned shapes: guarded edge variant of the same
 // kernel (f32) or a plain LDS-tiled kernel (f64 / ints; test-sized problems).
+#include <stdlib.h>
+
 #include "md_hip.h"
 
 namespace {
@@ -25,7 +28,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 16, LDP = 4;  // LDP: row pad (floats)
+constexpr int LDP = 4;  // LDS row pad (floats): keeps the transposing ds_write_b32 at <=2-way conflicts
 
 struct GemmArgs {
   const float *A, *B;
@@ -35,17 +38,22 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-// Tile loaders. KC = the operand's k axis is the contiguous one in memory.
-// Each thread moves 2 x 16 B per operand per k-step.
-template <bool KC, bool EDGE>
+// Tile loaders for a ROWS x BK operand tile, 256 threads, 16 B per thread per pass.
+// KC = the operand's k axis is the contiguous one in memory (row-major A, or B given as Bt).
+template <int ROWS, int BK, bool KC, bool EDGE>
 __device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t rs, int64_t ks, int64_t row0, int64_t k0,
-                                          int64_t rows, int64_t K, f32x4 (&r)[2]) {
+                                          int64_t rows, int64_t K, f32x4 (&r)[ROWS * BK / 1024]) {
+  constexpr int PASSES = ROWS * BK / 1024;
+  constexpr int TPR = BK / 4;            // KC: threads per row
+  constexpr int RPP = 256 / TPR;         // KC: rows per pass
+  constexpr int TPK = ROWS / 4;          // !KC: threads per k-row
+  constexpr int KPP = 256 / TPK;         // !KC: k-rows per pass
   const int t = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < PASSES; ++i) {
     int row, k;
-    if constexpr (KC) { row = (t >> 2) + 64 * i; k = (t & 3) * 4; }
-    else { k = (t >> 5) + 8 * i; row = (t & 31) * 4; }
+    if constexpr (KC) { row = t / TPR + RPP * i; k = (t % TPR) * 4; }
+    else { k = t / TPK + KPP * i; row = (t % TPK) * 4; }
     if constexpr (!EDGE) {
       r[i] = *reinterpret_cast<const f32x4 *>(P + (row0 + row) * rs + (k0 + k) * ks);
     } else {
@@ -57,24 +65,28 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t r
     }
   }
 }
-template <bool KC>
-__device__ __forceinline__ void store_tile(float (*S)[BM + LDP], const f32x4 (&r)[2]) {
+template <int ROWS, int BK, bool KC>
+__device__ __forceinline__ void store_tile(float (*S)[ROWS + LDP], const f32x4 (&r)[ROWS * BK / 1024]) {
+  constexpr int PASSES = ROWS * BK / 1024;
+  constexpr int TPR = BK / 4, RPP = 256 / TPR, TPK = ROWS / 4, KPP = 256 / TPK;
   const int t = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < PASSES; ++i) {
     if constexpr (KC) {
-      const int row = (t >> 2) + 64 * i, k = (t & 3) * 4;
+      const int row = t / TPR + RPP * i, k = (t % TPR) * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) S[k + j][row] = r[i][j];
     } else {
-      const int k = (t >> 5) + 8 * i, row = (t & 31) * 4;
+      const int k = t / TPK + KPP * i, row = (t % TPK) * 4;
       *reinterpret_cast<f32x4 *>(&S[k][row]) = r[i];
     }
   }
 }
 
-template <bool A_KC, bool B_KC, bool EDGE>
+// BM x BN block tile, BK k-step, 4 waves as 2 x 2, each wave (WTM*32) x (WTN*32).
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE>
 __global__ void __launch_bounds__(256) k_gemm_f32_mfma(GemmArgs g) {
+  constexpr int WTM = BM / 64, WTN = BN / 64;  // MFMA tiles per wave along m / n
   __shared__ float As[2][BK][BM + LDP];
   __shared__ float Bs[2][BK][BN + LDP];
 
@@ -93,45 +105,45 @@ __global__ void __launch_bounds__(256) k_gemm_f32_mfma(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l32 = lane & 31, h = lane >> 5;
 
-  f32x16 acc[2][2];
+  f32x16 acc[WTM][WTN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WTM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WTN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  f32x4 ra[2], rb[2];
+  f32x4 ra[BM * BK / 1024], rb[BN * BK / 1024];
   const int64_t nk = (g.K + BK - 1) / BK;
   // A tile rows = m (row stride a_ms), B tile rows = n (row stride b_ns)
-  load_tile<A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, 0, g.M, g.K, ra);
-  load_tile<B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, 0, g.N, g.K, rb);
-  store_tile<A_KC>(As[0], ra);
-  store_tile<B_KC>(Bs[0], rb);
+  load_tile<BM, BK, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, 0, g.M, g.K, ra);
+  load_tile<BN, BK, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, 0, g.N, g.K, rb);
+  store_tile<BM, BK, A_KC>(As[0], ra);
+  store_tile<BN, BK, B_KC>(Bs[0], rb);
   __syncthreads();
 
   int cur = 0;
   for (int64_t kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) {
-      load_tile<A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 1) * BK, g.M, g.K, ra);
-      load_tile<B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 1) * BK, g.N, g.K, rb);
+      load_tile<BM, BK, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 1) * BK, g.M, g.K, ra);
+      load_tile<BN, BK, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 1) * BK, g.N, g.K, rb);
     }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float a[2], b[2];
+      float a[WTM], b[WTN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[cur][kk + h][wm * 64 + i * 32 + l32];
+      for (int i = 0; i < WTM; ++i) a[i] = As[cur][kk + h][wm * (WTM * 32) + i * 32 + l32];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[cur][kk + h][wn * 64 + j * 32 + l32];
+      for (int j = 0; j < WTN; ++j) b[j] = Bs[cur][kk + h][wn * (WTN * 32) + j * 32 + l32];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
-      store_tile<A_KC>(As[cur ^ 1], ra);
-      store_tile<B_KC>(Bs[cur ^ 1], rb);
+      store_tile<BM, BK, A_KC>(As[cur ^ 1], ra);
+      store_tile<BN, BK, B_KC>(Bs[cur ^ 1], rb);
     }
     __syncthreads();
     cur ^= 1;
@@ -139,13 +151,13 @@ __global__ void __launch_bounds__(256) k_gemm_f32_mfma(GemmArgs g) {
 
   // C/D layout of the 32x32 accumulator: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WTM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t col = n0 + wn * 64 + j * 32 + l32;
+    for (int j = 0; j < WTN; ++j) {
+      const int64_t col = n0 + wn * (WTN * 32) + j * 32 + l32;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int64_t row = m0 + wm * (WTM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (!EDGE || (row < g.M && col < g.N)) C[row * g.c_ms + col * g.c_ns] = acc[i][j][r];
       }
     }
@@ -178,12 +190,43 @@ __global__ void __launch_bounds__(256) k_gemm_generic(MdGemm g) {
   if (row < g.M && col < g.N) C[row * g.c_ms + col * g.c_ns] = acc;
 }
 
+template <int BM, int BN, int BK, bool A_KC, bool B_KC>
+static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
+  ga.tiles_m = (int)((ga.M + BM - 1) / BM);
+  ga.tiles_n = (int)((ga.N + BN - 1) / BN);
+  edge = edge || (ga.M % BM) || (ga.N % BN) || (ga.K % BK);
+  dim3 grid((unsigned)(ga.tiles_m * ga.tiles_n), 1, (unsigned)batch);
+  if (edge) k_gemm_f32_mfma<BM, BN, BK, A_KC, B_KC, true><<<grid, 256, 0, md_stream()>>>(ga);
+  else k_gemm_f32_mfma<BM, BN, BK, A_KC, B_KC, false><<<grid, 256, 0, md_stream()>>>(ga);
+  return MD_LAUNCH_CHECK("matmul(f32 mfma)");
+}
+
+enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_128x128x32, CFG_COUNT };
+
+static int pick_cfg(const GemmArgs &ga, int64_t batch) {
+  if (const char *e = getenv("MDHIP_GEMM_CFG")) {  // experiments only
+    int v = atoi(e);
+    if (v >= 0 && v < CFG_COUNT) return v;
+  }
+  // Measured on MI355X (profiles/r1_gemm_tile_ab.log, random data, interleaved rounds):
+  // 256x128 wins whenever it still yields >= 2 blocks per CU (134 TF at 4096^3 and
+  // 8192x4096x4096); below that, smaller tiles keep >= 2 blocks per CU resident.
+  auto tiles = [&](int bm, int bn) { return ((ga.M + bm - 1) / bm) * ((ga.N + bn - 1) / bn) * batch; };
+  if (tiles(256, 128) >= 2 * MD_NUM_CUS) return CFG_256x128x16;
+  if (tiles(128, 128) >= 3 * MD_NUM_CUS) return CFG_128x128x16;
+  if (tiles(128, 64) >= 2 * MD_NUM_CUS) return CFG_128x64x16;
+  return CFG_64x64x16;
+}
+
 template <bool A_KC, bool B_KC>
 static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
-  dim3 grid((unsigned)(ga.tiles_m * ga.tiles_n), 1, (unsigned)batch);
-  if (edge) k_gemm_f32_mfma<A_KC, B_KC, true><<<grid, 256, 0, md_stream()>>>(ga);
-  else k_gemm_f32_mfma<A_KC, B_KC, false><<<grid, 256, 0, md_stream()>>>(ga);
-  return MD_LAUNCH_CHECK("matmul(f32 mfma)");
+  switch (pick_cfg(ga, batch)) {
+    case CFG_64x64x16: return launch_cfg<64, 64, 16, A_KC, B_KC>(ga, batch, edge);
+    case CFG_128x64x16: return launch_cfg<128, 64, 16, A_KC, B_KC>(ga, batch, edge);
+    case CFG_256x128x16: return launch_cfg<256, 128, 16, A_KC, B_KC>(ga, batch, edge);
+    case CFG_128x128x32: return launch_cfg<128, 128, 32, A_KC, B_KC>(ga, batch, edge);
+    default: return launch_cfg<128, 128, 16, A_KC, B_KC>(ga, batch, edge);
+  }
 }
 
 struct HipExec {
@@ -201,12 +244,11 @@ struct HipExec {
         ga.a_bs = g.a_bs; ga.a_ms = g.a_ms; ga.a_ks = g.a_ks;
         ga.b_bs = g.b_bs; ga.b_ks = g.b_ks; ga.b_ns = g.b_ns;
         ga.c_bs = g.c_bs; ga.c_ms = g.c_ms; ga.c_ns = g.c_ns;
-        ga.tiles_m = (int)((g.M + BM - 1) / BM);
-        ga.tiles_n = (int)((g.N + BN - 1) / BN);
+        ga.tiles_m = ga.tiles_n = 0;  // set per tile config
         // prefer the layout that allows 16-B loads; A_KC means "vectorise A along k"
         const bool A_KC = a_kc && !(a_mc && g.a_ks != 1), B_KC = b_kc && !(b_nc && g.b_ks != 1);
         auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
-        bool edge = (g.M % BM) || (g.N % BN) || (g.K % BK) || !al16(g.a) || !al16(g.b);
+        bool edge = !al16(g.a) || !al16(g.b);
         // the vector axis' partner stride must keep rows 16-B aligned
         edge = edge || ((A_KC ? g.a_ms : g.a_ks) & 3) || ((B_KC ? g.b_ns : g.b_ks) & 3) || (g.a_bs & 3) || (g.b_bs & 3);
         if (A_KC && B_KC) return launch_mfma<true, true>(ga, g.batch, edge);

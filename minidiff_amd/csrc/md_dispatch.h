@@ -138,6 +138,23 @@ template <class X> int md_binary_dispatch(int op, const mdhip_array *a, const md
       default: return md_fail(MDHIP_ETYPE, "ufunc not supported for dtype bool");
     }
   }
+  // x ** c with a host-scalar float exponent (the tape's x**2, x**1, x**0.5: definitions.py:386-391,
+  // 509): one read + one write with the exponent folded into the kernel instead of a generic pow
+  if (op == MDHIP_B_POW && b->is_scalar && !a->is_scalar && md_dtype_is_float(cdt) && a->dtype == cdt) {
+    const double e = md_dtype_is_float(b->dtype) ? b->scalar_f : (double)b->scalar_i;
+    MdIter it2;
+    const mdhip_array *ops2[2] = {a, out};
+    MD_TRY(md_build_iter(&it2, 2, ops2, out));
+#define MD_POW_AS(F)                                                                   \
+    return cdt == MDHIP_F32 ? X::template unary<F, float, float>(it2, a, out)            \
+                            : X::template unary<F, double, double>(it2, a, out)
+    if (e == 2.0) { MD_POW_AS(USquare); }
+    if (e == 1.0) { MD_POW_AS(UCopy); }
+    if (e == 0.5) { MD_POW_AS(UPowHalf); }
+    if (e == -1.0) { MD_POW_AS(URecip); }
+    if (e == 0.0) { MD_POW_AS(UOne); }
+#undef MD_POW_AS
+  }
   switch (op) {
 #define MD_B_NUM(code, F) \
   case code: MD_NUM_SWITCH(cdt, T, return (X::template binary<F, T, T>(it, a, b, out)))

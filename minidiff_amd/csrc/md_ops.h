@@ -154,6 +154,23 @@ MD_UFLOAT(UExp, md_exp)
 MD_UFLOAT(ULog, md_log)
 MD_UFLOAT(USqrt, md_sqrt)
 #undef MD_UFLOAT
+// power with a host-scalar exponent is dispatched to these (same values as BPow's shortcuts)
+struct USquare {
+  template <class T> static MD_HD T apply(T x) { return x * x; }
+};
+struct URecip {
+  template <class T> static MD_HD T apply(T x) { return (T)1 / x; }
+};
+struct UOne {
+  template <class T> static MD_HD T apply(T) { return (T)1; }
+};
+struct UPowHalf {
+  template <class T> static MD_HD T apply(T a) {
+    if (a > (T)0 && a != (T)INFINITY) return md_sqrt(a);
+    if (a == (T)0) return (T)0;
+    return md_pow(a, (T)0.5);
+  }
+};
 struct UInvert {  // integers: bitwise not. (bool is routed to ULogicalNot.)
   template <class T> static MD_HD T apply(T x) { return (T)~x; }
 };
@@ -254,7 +271,10 @@ struct BPow {
       if (b == (T)2) return a * a;
       if (b == (T)1) return a;
       if (b == (T)0) return (T)1;
-      if (b == (T)0.5 && a >= (T)0 && a == a && a != (T)INFINITY) return md_sqrt(a);
+      if (b == (T)0.5) {  // pow(+-0, .5) = +0; sqrt(-0) would be -0
+        if (a > (T)0 && a != (T)INFINITY) return md_sqrt(a);
+        if (a == (T)0) return (T)0;
+      }
       if (b == (T)-1) return (T)1 / a;
       return md_pow(a, b);
     } else {

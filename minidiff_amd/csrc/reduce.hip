@@ -67,16 +67,25 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows(MdRedPlan pl, const vo
       if ((int64_t)threadIdx.x < head) acc = R::combine(acc, p[r0 + threadIdx.x]);
       const int64_t v0 = r0 + head;
       const int64_t nvec = (r1 - v0) / V;
-      Tacc a2[V];
+      // two independent 16-B loads per lane per trip, 2*V accumulators
+      Tacc a2[V], a3[V];
 #pragma unroll
-      for (int j = 0; j < V; ++j) a2[j] = R::template identity<Tacc>();
-      for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) {
-        MdVec<Tacc, V> t = *reinterpret_cast<const MdVec<Tacc, V> *>(p + v0 + i * V);
+      for (int j = 0; j < V; ++j) { a2[j] = R::template identity<Tacc>(); a3[j] = a2[j]; }
+      const MdVec<Tacc, V> *pv = reinterpret_cast<const MdVec<Tacc, V> *>(p + v0);
+      int64_t i = threadIdx.x;
+      for (; i + blockDim.x < nvec; i += 2 * blockDim.x) {
+        MdVec<Tacc, V> t = pv[i];
+        MdVec<Tacc, V> u = pv[i + blockDim.x];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { a2[j] = R::combine(a2[j], t.v[j]); a3[j] = R::combine(a3[j], u.v[j]); }
+      }
+      if (i < nvec) {
+        MdVec<Tacc, V> t = pv[i];
 #pragma unroll
         for (int j = 0; j < V; ++j) a2[j] = R::combine(a2[j], t.v[j]);
       }
 #pragma unroll
-      for (int j = 0; j < V; ++j) acc = R::combine(acc, a2[j]);
+      for (int j = 0; j < V; ++j) acc = R::combine(acc, R::combine(a2[j], a3[j]));
       const int64_t t0 = v0 + nvec * V;
       if (t0 + (int64_t)threadIdx.x < r1) acc = R::combine(acc, p[t0 + threadIdx.x]);
     }

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""A/B the fp32 MFMA GEMM tile configs in ONE process (guide §5.4 rule 24):
+interleaved rounds over configs x layouts x shapes, HIP-event timing, random data.
+MDHIP_GEMM_CFG is read by libmdhip at every launch (experiments only)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from minidiff_amd import _capi, ndarray as nd  # noqa: E402
+
+CFGS = {0: "128x128x16", 1: "64x64x16", 2: "128x64x16", 3: "256x128x16", 4: "128x128x32"}
+
+
+def main():
+    lib = _capi.load()
+    shapes = [(4096, 4096, 4096), (2048, 2048, 2048), (8192, 4096, 4096), (1024, 4096, 4096), (4096, 1024, 4096)]
+    if len(sys.argv) > 1:
+        shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+    rng = np.random.default_rng(0)
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    lib.event_create(C.byref(e0)); lib.event_create(C.byref(e1))
+    ms = C.c_float()
+    for (M, K, N) in shapes:
+        A = nd.asarray(rng.standard_normal((M, K), dtype=np.float32))
+        B = nd.asarray(rng.standard_normal((K, N), dtype=np.float32))
+        At = nd.asarray(np.ascontiguousarray(A.get().T))
+        Bt = nd.asarray(np.ascontiguousarray(B.get().T))
+        ref = None
+        res = {}
+        for rnd in range(3):
+            for cfg in CFGS:
+                os.environ["MDHIP_GEMM_CFG"] = str(cfg)
+                for tag, a, b in (("NN", A, B), ("NT", A, Bt.T), ("TN", At.T, B)):
+                    nd.matmul(a, b)  # warm
+                    lib.event_record(e0)
+                    for _ in range(5):
+                        out = nd.matmul(a, b)
+                    lib.event_record(e1)
+                    lib.event_elapsed_ms(e0, e1, C.byref(ms))
+                    tf = 5 * 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
+                    res.setdefault((cfg, tag), []).append(tf)
+                    if rnd == 0:
+                        h = out.get()
+                        if ref is None:
+                            ref = h
+                        assert np.abs(h - ref).max() / np.abs(ref).max() < 2e-6, (cfg, tag)
+        print(f"M={M} K={K} N={N}")
+        for cfg, name in CFGS.items():
+            print("   %-11s " % name + "  ".join("%s med %6.1f max %6.1f TF" % (t, sorted(res[(cfg, t)])[1], max(res[(cfg, t)])) for t in ("NN", "NT", "TN")))
+    del os.environ["MDHIP_GEMM_CFG"]
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+"""The reference's own test strategy (tests/test_ops.py:25-62) replayed on this
+repo's engines: for each of its 39 op tests, (a) forward vs the backend function,
+(b) autodiff gradient vs central finite differences (h=1e-2) through the
+half-squared-sum loss, both at rtol 1e-3 / atol 1e-4 with NaNs masked.
+
+Inputs are seeded (the reference draws unseeded randn); shapes and argument
+forms are the reference's. The reference's known-failing forms (SURVEY.md §4:
+max/min/std gradient functions raise for tuple/None axes) must fail the SAME way
+on the device engine and on the NumPy-oracle engine — they are not "fixed"."""
+import random
+
+import numpy as np
+import pytest
+
+from minidiff_amd.fdcheck import compute_grads
+
+gpu = pytest.mark.gpu
+
+
+def _np(x):
+    d = x._data if hasattr(x, "_data") else x
+    return d.get() if hasattr(d, "get") else np.asarray(d)
+
+
+def filter_nan(a, b):
+    c = np.isnan(a) | np.isnan(b)
+    return np.where(c, 0, a), np.where(c, 0, b)
+
+
+def perform_test(md, func, backend_func, args, kwargs, exclude=None):
+    out = _np(func(*args, **kwargs))
+    comp = _np(backend_func(*[md.try_unwrap(x) for x in args], **{k: md.try_unwrap(v) for k, v in kwargs.items()}))
+
+    def loss_func(*loss_args):
+        actual = func(*loss_args, **kwargs)
+        return md.sum((md.zeros_like(actual) - actual) ** 2) / 2
+
+    if out.size != 1:
+        out, comp = filter_nan(out, comp)
+    assert np.allclose(out, comp, rtol=1e-3, atol=1e-4)
+    manual, auto = compute_grads(md, *args, func=loss_func, exclude=exclude, h=1e-2)
+    for m, a in zip(manual, auto):
+        if m is None and a is None:
+            continue
+        m, a = filter_nan(_np(m), _np(a))
+        assert np.allclose(m, a, rtol=1e-3, atol=1e-4), np.max(np.abs(m - a))
+
+
+def _axis(rnd):
+    return rnd.choice([tuple(rnd.sample(range(4), k=rnd.randint(0, 4))), None])
+
+
+def _t(md, rng, *shape):
+    return md.Tensor(rng.standard_normal(shape), allow_grad=True)
+
+
+S = (2, 2, 2, 2)
+# name -> builder(md, B, rng, rnd) -> (func, backend_func, args, kwargs, exclude)
+CASES = {
+    "ravel": lambda md, B, g, r: (md.ravel, B.ravel, [_t(md, g, *S)], {}, None),
+    "flatten": lambda md, B, g, r: (md.flatten, B.flatten, [_t(md, g, *S)], {}, None),
+    "squeeze": lambda md, B, g, r: (md.squeeze, B.squeeze, [_t(md, g, 1, 2, 1, 2)], {}, None),
+    "expand_dims": lambda md, B, g, r: (md.expand_dims, B.expand_dims, [_t(md, g, *S), tuple(r.sample(range(4), k=r.randint(0, 4)))], {}, None),
+    "max": lambda md, B, g, r: (md.max, B.max, [_t(md, g, *S)], {"axis": _axis(r)}, None),
+    "min": lambda md, B, g, r: (md.min, B.min, [_t(md, g, *S)], {"axis": _axis(r)}, None),
+    "where": lambda md, B, g, r: (lambda c=md.Tensor(g.integers(0, 2, S)): (md.where, B.where, [c, _t(md, g, *S), _t(md, g, *S)], {}, [c]))(),
+    "prod": lambda md, B, g, r: (md.prod, B.prod, [_t(md, g, *S)], {"axis": _axis(r)}, None),
+    "std": lambda md, B, g, r: (md.std, B.std, [_t(md, g, *S)], {"axis": _axis(r)}, None),
+    "transpose": lambda md, B, g, r: (md.transpose, B.transpose, [_t(md, g, *S)], {"axes": tuple(g.permutation(4))}, None),
+    "swapaxes": lambda md, B, g, r: (md.swapaxes, B.swapaxes, [_t(md, g, *S), r.randint(0, 3), r.randint(0, 3)], {}, None),
+    "flip": lambda md, B, g, r: (md.flip, B.flip, [_t(md, g, *S)], {"axis": _axis(r)}, None),
+    "dot": lambda md, B, g, r: (md.dot, B.dot, [_t(md, g, 2), _t(md, g, 2)], {}, None),
+    "broadcast_to": lambda md, B, g, r: (md.broadcast_to, B.broadcast_to, [_t(md, g, *S), (4, 2, 2, 2, 2)], {}, None),
+    "atleast_1d": lambda md, B, g, r: (md.atleast_1d, B.atleast_1d, [_t(md, g, *S)], {}, None),
+    "atleast_2d": lambda md, B, g, r: (md.atleast_2d, B.atleast_2d, [_t(md, g, *S)], {}, None),
+    "atleast_3d": lambda md, B, g, r: (md.atleast_3d, B.atleast_3d, [_t(md, g, *S)], {}, None),
+    "copy": lambda md, B, g, r: (md.copy, B.copy, [_t(md, g, *S)], {}, None),
+    "getitem": lambda md, B, g, r: (lambda k=md.Tensor(g.integers(0, 2, (4,))): (md.getitem, lambda x, key: x[key], [_t(md, g, *S), k], {}, [k]))(),
+    "clip": lambda md, B, g, r: (md.clip, B.clip, [_t(md, g, *S), r.uniform(0, 10), r.uniform(-10, 0)], {}, None),
+    "reshape": lambda md, B, g, r: (md.reshape, B.reshape, [_t(md, g, *S), (4, 4)], {}, None),
+    "matmul": lambda md, B, g, r: (md.matmul, B.matmul, [_t(md, g, 10, 30), _t(md, g, 30, 20)], {}, None),
+    "tensordot": lambda md, B, g, r: (md.tensordot, B.tensordot, [_t(md, g, *S), _t(md, g, *S)], {}, None),
+    "add": lambda md, B, g, r: (md.add, B.add, [_t(md, g, *S), _t(md, g, *S)], {}, None),
+    "subtract": lambda md, B, g, r: (md.subtract, B.subtract, [_t(md, g, *S), _t(md, g, *S)], {}, None),
+    "multiply": lambda md, B, g, r: (md.multiply, B.multiply, [_t(md, g, *S), _t(md, g, *S)], {}, None),
+    "true_divide": lambda md, B, g, r: (md.true_divide, B.true_divide, [_t(md, g, *S), md.Tensor(g.standard_normal(S) + np.where(g.random(S) > 0.5, 3.0, -3.0), allow_grad=True)], {}, None),
+    "power": lambda md, B, g, r: (md.power, B.power, [_t(md, g, *S), _t(md, g, *S)], {}, None),
+    "cos": lambda md, B, g, r: (md.cos, B.cos, [_t(md, g, *S)], {}, None),
+    "sin": lambda md, B, g, r: (md.sin, B.sin, [_t(md, g, *S)], {}, None),
+    "tan": lambda md, B, g, r: (md.tan, B.tan, [md.Tensor(g.uniform(-1.0, 1.0, S), allow_grad=True)], {}, None),
+    "cosh": lambda md, B, g, r: (md.cosh, B.cosh, [_t(md, g, *S)], {}, None),
+    "sinh": lambda md, B, g, r: (md.sinh, B.sinh, [_t(md, g, *S)], {}, None),
+    "tanh": lambda md, B, g, r: (md.tanh, B.tanh, [_t(md, g, *S)], {}, None),
+    "exp": lambda md, B, g, r: (md.exp, B.exp, [_t(md, g, *S)], {}, None),
+    "log": lambda md, B, g, r: (md.log, B.log, [_t(md, g, *S)], {}, None),
+    "sum": lambda md, B, g, r: (md.sum, B.sum, [_t(md, g, *S)], {"axis": _axis(r)}, None),
+    "mean": lambda md, B, g, r: (md.mean, B.mean, [_t(md, g, *S)], {"axis": _axis(r)}, None),
+    "absolute": lambda md, B, g, r: (md.absolute, B.absolute, [_t(md, g, *S)], {}, None),
+}
+assert len(CASES) == 39
+
+
+def _outcome(md, name, trial):
+    seed = hash((name, trial)) % (2 ** 31) if False else (sum(map(ord, name)) * 101 + trial)
+    g, r = np.random.default_rng(seed), random.Random(seed)
+    func, bfunc, args, kwargs, exclude = CASES[name](md, md.backend, g, r)
+    try:
+        with np.errstate(all="ignore"):
+            perform_test(md, func, bfunc, args, kwargs, exclude)
+        return "pass"
+    except AssertionError:
+        return "mismatch"
+    except Exception as e:  # the reference's defects surface as exceptions
+        return "raises:" + type(e).__name__
+
+
+# forms that fail in the reference itself — outcome must merely agree with the oracle engine
+REFERENCE_DEFECTS = {"max", "min", "std"}
+
+
+def _run(engines, name):
+    dev, oracle = engines
+    for trial in range(5):
+        o = _outcome(oracle, name, trial)
+        d = _outcome(dev, name, trial)
+        assert d == o, (name, trial, d, o)
+        if name not in REFERENCE_DEFECTS:
+            assert d == "pass", (name, trial, d)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reference_style_cpu(engines, on_gpu, name):
+    if on_gpu:
+        pytest.skip("GPU present: covered by the gpu-marked twin")
+    _run(engines, name)
+
+
+@gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reference_style_gpu(engines, on_gpu, lib, name):
+    assert on_gpu and lib.target == "hip:gfx950"
+    _run(engines, name)
