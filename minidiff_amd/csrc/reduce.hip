@@ -45,15 +45,17 @@ template <class R, class T> __device__ __forceinline__ T md_block_reduce(T v, T 
 
 // ------------------------------------------------------------------- rows ------
 template <class R, class Tacc, class Tdst, bool FINAL>
-__global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows(MdRedPlan pl, const void *x, int xdt, int64_t splits, int64_t chunk, Tdst *dst) {
+__global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows(MdRedPlan pl, const void *x, int xdt, int64_t splits, Tdst *dst) {
   __shared__ Tacc smem[MD_BLOCK / 64];
   const int64_t b = blockIdx.x;
   const int64_t o = b / splits, s = b - o * splits;
   int64_t xo, oo;
   md_red_kept_offsets(pl, o, &xo, &oo);
-  const int64_t r0 = s * chunk;
-  int64_t r1 = r0 + chunk;
-  if (r1 > pl.n_red) r1 = pl.n_red;
+  // the `splits` blocks of one row sweep it together: lane (s, tid) takes items
+  // s*blockDim + tid, + splits*blockDim, ... (neighbouring blocks read neighbouring
+  // lines at the same time, like the streaming elementwise kernels)
+  const int64_t lane0 = s * blockDim.x + threadIdx.x, step = splits * blockDim.x;
+  const int64_t n = pl.n_red;
   Tacc acc = R::template identity<Tacc>();
   constexpr int V = 16 / sizeof(Tacc);
   bool vec = false;
@@ -61,21 +63,19 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows(MdRedPlan pl, const vo
   if (vec) {
     if constexpr (sizeof(Tacc) >= 4) {
       const Tacc *p = (const Tacc *)x + xo;
-      // peel to 16-B alignment, then V-wide loads with independent accumulators
-      int64_t head = (V - (int64_t)(((uintptr_t)(p + r0) / sizeof(Tacc)) % V)) % V;
-      if (head > r1 - r0) head = r1 - r0;
-      if ((int64_t)threadIdx.x < head) acc = R::combine(acc, p[r0 + threadIdx.x]);
-      const int64_t v0 = r0 + head;
-      const int64_t nvec = (r1 - v0) / V;
-      // two independent 16-B loads per lane per trip, 2*V accumulators
+      // peel to 16-B alignment, then V-wide loads, two in flight per lane
+      int64_t head = (V - (int64_t)(((uintptr_t)p / sizeof(Tacc)) % V)) % V;
+      if (head > n) head = n;
+      if (lane0 < head) acc = R::combine(acc, p[lane0]);
+      const int64_t nvec = (n - head) / V;
       Tacc a2[V], a3[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) { a2[j] = R::template identity<Tacc>(); a3[j] = a2[j]; }
-      const MdVec<Tacc, V> *pv = reinterpret_cast<const MdVec<Tacc, V> *>(p + v0);
-      int64_t i = threadIdx.x;
-      for (; i + blockDim.x < nvec; i += 2 * blockDim.x) {
+      const MdVec<Tacc, V> *pv = reinterpret_cast<const MdVec<Tacc, V> *>(p + head);
+      int64_t i = lane0;
+      for (; i + step < nvec; i += 2 * step) {
         MdVec<Tacc, V> t = pv[i];
-        MdVec<Tacc, V> u = pv[i + blockDim.x];
+        MdVec<Tacc, V> u = pv[i + step];
 #pragma unroll
         for (int j = 0; j < V; ++j) { a2[j] = R::combine(a2[j], t.v[j]); a3[j] = R::combine(a3[j], u.v[j]); }
       }
@@ -86,14 +86,14 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows(MdRedPlan pl, const vo
       }
 #pragma unroll
       for (int j = 0; j < V; ++j) acc = R::combine(acc, R::combine(a2[j], a3[j]));
-      const int64_t t0 = v0 + nvec * V;
-      if (t0 + (int64_t)threadIdx.x < r1) acc = R::combine(acc, p[t0 + threadIdx.x]);
+      const int64_t t0 = head + nvec * V;
+      if (t0 + lane0 < n) acc = R::combine(acc, p[t0 + lane0]);
     }
   } else if (pl.nr == 1) {
     const int64_t rs = pl.rx[0];
-    for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) acc = R::combine(acc, md_load<Tacc>(x, xdt, xo + r * rs));
+    for (int64_t r = lane0; r < n; r += step) acc = R::combine(acc, md_load<Tacc>(x, xdt, xo + r * rs));
   } else {
-    for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) acc = R::combine(acc, md_load<Tacc>(x, xdt, xo + md_red_offset(pl, r)));
+    for (int64_t r = lane0; r < n; r += step) acc = R::combine(acc, md_load<Tacc>(x, xdt, xo + md_red_offset(pl, r)));
   }
   acc = md_block_reduce<R>(acc, smem);
   if (threadIdx.x == 0) {
@@ -239,20 +239,18 @@ struct HipExec {
       return rc;
     }
     if (rows_ok) {
+      // ~2048 blocks in total; each block should still see >= 4096 items
       int64_t splits = 2048 / n_out;
       const int64_t max_splits = ceil_div(n_red, 4096);
       if (splits > max_splits) splits = max_splits;
       if (splits < 1) splits = 1;
-      int64_t chunk = ceil_div(n_red, splits);
-      chunk = ceil_div(chunk, 1024) * 1024;
-      splits = ceil_div(n_red, chunk);
       if (splits == 1) {
-        k_reduce_rows<R, Tacc, To, true><<<(unsigned)n_out, MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, 1, chunk, (To *)out->data);
+        k_reduce_rows<R, Tacc, To, true><<<(unsigned)n_out, MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, 1, (To *)out->data);
         return MD_LAUNCH_CHECK("reduce(rows)");
       }
       void *partial = nullptr;
       MD_TRY(mdhip_alloc((size_t)(splits * n_out) * sizeof(Tacc), &partial));
-      k_reduce_rows<R, Tacc, Tacc, false><<<(unsigned)(n_out * splits), MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, splits, chunk, (Tacc *)partial);
+      k_reduce_rows<R, Tacc, Tacc, false><<<(unsigned)(n_out * splits), MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, splits, (Tacc *)partial);
       k_finish_rows<R, Tacc, To><<<(unsigned)n_out, MD_BLOCK, 0, st>>>(pl, (const Tacc *)partial, splits, (To *)out->data);
       int rc = MD_LAUNCH_CHECK("reduce(rows,split)");
       mdhip_free(partial);

@@ -28,6 +28,17 @@ from contextvars import ContextVar
 from math import prod as _pyprod
 
 
+def _visit(node, seen, out):
+    if node is None:
+        return
+    for t in node.tensor_inputs:
+        if id(t) in seen:
+            continue
+        seen.add(id(t))
+        _visit(t.op_node, seen, out)
+        out.append(t)
+
+
 def build_engine(B, name: str = "engine"):
     """Create the md-like namespace (Tensor, ops, helpers) over backend table `B`."""
     E = types.SimpleNamespace()
@@ -148,19 +159,12 @@ def build_engine(B, name: str = "engine"):
             return f"{self.name}({', '.join(str(x) for x in self.inputs)})"
 
     def _toposort(root):
+        """Post-order DFS over tensor inputs (inputs before their consumers), the
+        reference's visiting order (topology.py:106-128). Deliberately not a
+        self-referencing closure: that would form a reference cycle holding every
+        intermediate (hundreds of MB of HBM each) until Python's cyclic GC runs."""
         seen, out = set(), []
-
-        def visit(node):
-            if node is None:
-                return
-            for t in node.tensor_inputs:
-                if id(t) in seen:
-                    continue
-                seen.add(id(t))
-                visit(t.op_node)
-                out.append(t)
-
-        visit(root)
+        _visit(root, seen, out)
         return out
 
     E.OpNode = Node
