@@ -1,6 +1,7 @@
 // md_hip.h — device-side helpers shared by the .hip translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "md_dispatch.h"
 
@@ -12,7 +13,16 @@ int md_hip_check(hipError_t e, const char *what);
 // MI355X: 256 CUs. Streaming kernels cap the grid and stride (guide §6 G11).
 constexpr int MD_NUM_CUS = 256;
 constexpr int MD_BLOCK = 256;
-static inline int md_grid_for(int64_t work_items, int per_block = MD_BLOCK, int max_blocks = MD_NUM_CUS * 8) {
+static inline int md_max_blocks() {
+  static int v = [] {
+    const char *e = getenv("MDHIP_MAX_BLOCKS");  // tuning knob for experiments
+    int n = e ? atoi(e) : 0;
+    return n > 0 ? n : MD_NUM_CUS * 8;
+  }();
+  return v;
+}
+static inline int md_grid_for(int64_t work_items, int per_block = MD_BLOCK, int max_blocks = 0) {
+  if (max_blocks <= 0) max_blocks = md_max_blocks();
   int64_t b = (work_items + per_block - 1) / per_block;
   if (b < 1) b = 1;
   if (b > max_blocks) b = max_blocks;

@@ -158,6 +158,67 @@ __global__ void __launch_bounds__(MD_BLOCK) k_finish_cols(MdRedPlan pl, const Ta
   out[oo] = md_cast<To>(acc);
 }
 
+// --------------------------------------------------------- cols, vectorised ------
+// The reduce-to-shape of the broadcast-gradient path at scale (bias gradient:
+// sum(g[8192,4096], axis=0)). Block = 64 column groups x 4 row lanes; a lane owns
+// V adjacent columns (one 16-B load per row), a wave reads 1 KiB of one row per
+// instruction, the four waves of a block walk four different rows, four rows in
+// flight per lane (64 B/lane). Row lanes are combined through LDS, row chunks
+// through a partial buffer [split][n_out] reduced by the same kernel.
+template <class R, class Tacc, class Tdst, bool FINAL>
+__global__ void __launch_bounds__(MD_BLOCK) k_reduce_cols_vec(const Tacc *__restrict__ x, int64_t n_out, int64_t n_red, int64_t rs,
+                                                             int64_t chunk, Tdst *__restrict__ dst) {
+  constexpr int V = 16 / sizeof(Tacc);
+  __shared__ Tacc smem[3][64][V];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t col = ((int64_t)blockIdx.x * 64 + cx) * V;
+  const int64_t s = blockIdx.y;
+  const int64_t r0 = s * chunk;
+  int64_t r1 = r0 + chunk;
+  if (r1 > n_red) r1 = n_red;
+  Tacc acc[4][V];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[u][j] = R::template identity<Tacc>();
+  if (col < n_out) {
+    const Tacc *p = x + col;
+    int64_t r = r0 + ry;
+    for (; r + 12 < r1; r += 16) {
+      MdVec<Tacc, V> t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const MdVec<Tacc, V> *>(p + (r + 4 * u) * rs);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[u][j] = R::combine(acc[u][j], t[u].v[j]);
+    }
+    for (; r < r1; r += 4) {
+      MdVec<Tacc, V> t = *reinterpret_cast<const MdVec<Tacc, V> *>(p + r * rs);
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[0][j] = R::combine(acc[0][j], t.v[j]);
+    }
+  }
+  Tacc tot[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) tot[j] = R::combine(R::combine(acc[0][j], acc[1][j]), R::combine(acc[2][j], acc[3][j]));
+  if (ry > 0) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) smem[ry - 1][cx][j] = tot[j];
+  }
+  __syncthreads();
+  if (ry == 0 && col < n_out) {
+    MdVec<Tdst, V> o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      Tacc v = R::combine(R::combine(tot[j], smem[0][cx][j]), R::combine(smem[1][cx][j], smem[2][cx][j]));
+      o.v[j] = md_cast<Tdst>(v);
+    }
+    Tdst *d = FINAL ? dst + col : dst + s * n_out + col;
+    *reinterpret_cast<MdVec<Tdst, V> *>(d) = o;
+  }
+}
+
 // ---------------------------------------------------------------- generic ------
 template <class R, class Tacc, class To>
 __global__ void __launch_bounds__(MD_BLOCK) k_reduce_generic(MdRedPlan pl, const void *x, int xdt, To *out) {
@@ -218,6 +279,34 @@ struct HipExec {
     const bool rows_ok = n_red >= 256 && n_out < (1ll << 30);
     const bool cols_ok = pl.nk >= 1 && pl.kx[pl.nk - 1] == 1 && n_out >= 64;
     if (cols_ok && (!rows_ok || n_out >= 1024)) {
+      if constexpr (sizeof(Tacc) >= 4 && std::is_same<Tacc, To>::value) {
+        constexpr int V = 16 / sizeof(Tacc);
+        const bool vec_ok = pl.nk == 1 && pl.nr == 1 && pl.ko[0] == 1 && x->dtype == md_dtype_of<Tacc>::value &&
+                            (n_out % V) == 0 && (pl.rx[0] % V) == 0 && ((uintptr_t)x->data & 15) == 0 &&
+                            ((uintptr_t)out->data & 15) == 0 && n_red >= 16;
+        if (vec_ok) {
+          const int64_t bxv = ceil_div(n_out, 64 * V);
+          int64_t splits = 1024 / bxv;
+          if (splits > n_red / 64) splits = n_red / 64;
+          if (splits > 65535) splits = 65535;
+          if (splits < 1) splits = 1;
+          const int64_t chunk = ceil_div(ceil_div(n_red, splits), 16) * 16;
+          splits = ceil_div(n_red, chunk);
+          const Tacc *xp = (const Tacc *)x->data;
+          if (splits == 1) {
+            k_reduce_cols_vec<R, Tacc, To, true><<<dim3((unsigned)bxv, 1), MD_BLOCK, 0, st>>>(xp, n_out, n_red, pl.rx[0], chunk, (To *)out->data);
+            return MD_LAUNCH_CHECK("reduce(cols,vec)");
+          }
+          void *partial = nullptr;
+          MD_TRY(mdhip_alloc((size_t)(splits * n_out) * sizeof(Tacc), &partial));
+          k_reduce_cols_vec<R, Tacc, Tacc, false><<<dim3((unsigned)bxv, (unsigned)splits), MD_BLOCK, 0, st>>>(xp, n_out, n_red, pl.rx[0], chunk, (Tacc *)partial);
+          const int64_t chunk2 = ceil_div(splits, 16) * 16;
+          k_reduce_cols_vec<R, Tacc, To, true><<<dim3((unsigned)bxv, 1), MD_BLOCK, 0, st>>>((const Tacc *)partial, n_out, splits, n_out, chunk2, (To *)out->data);
+          int rc = MD_LAUNCH_CHECK("reduce(cols,vec,split)");
+          mdhip_free(partial);
+          return rc;
+        }
+      }
       const int64_t bx = ceil_div(n_out, MD_BLOCK);
       int64_t splits = 1024 / bx;
       if (splits > n_red / 32) splits = n_red / 32;

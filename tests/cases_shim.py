@@ -125,6 +125,14 @@ def case_reduce_large(nd):
     check("argmax/rows", nd.argmax(dx, axis=1), np.argmax(x, axis=1))
     check("argmin/flat", nd.argmin(dx), np.argmin(x))
     check("sum/T-all", nd.sum(dx.T), np.sum(x.T), rtol=1e-5)
+    w = rng.standard_normal((1500, 768)).astype(np.float32)  # vectorised column reduce (+ split + finishing pass)
+    dw = nd.asarray(w)
+    check("sum/cols-vec", nd.sum(dw, axis=0), np.sum(w, axis=0), rtol=1e-5)
+    check("max/cols-vec", nd.max(dw, axis=0), np.max(w, axis=0))
+    check("sum/cols-vec-view", nd.sum(dw[4:, 8:520], axis=(0,)), np.sum(w[4:, 8:520], axis=(0,)), rtol=1e-5)
+    w64 = rng.standard_normal((515, 256))
+    check("sum/cols-vec-f64", nd.sum(nd.asarray(w64), axis=0), np.sum(w64, axis=0), rtol=1e-12)
+    check("sum/cols-short", nd.sum(dw[:17], axis=0), np.sum(w[:17], axis=0), rtol=1e-5)
     y = rng.standard_normal((300_001,)).astype(np.float32)
     check("sum/1d-odd", nd.sum(nd.asarray(y)), np.sum(y), rtol=1e-5)
     check("sum/1d-offset", nd.sum(nd.asarray(y)[3:]), np.sum(y[3:]), rtol=1e-5)
