@@ -12,9 +12,11 @@
 //   block tile BM x BN x BK (128x128x16 by default; smaller tiles when the problem
 //   would otherwise leave CUs with <3 resident blocks), 4 waves (2x2), each wave
 //   (BM/2)x(BN/2) in 32x32 MFMA tiles (64 accumulator VGPRs at 128x128). Operands are staged in LDS k-major ([k][m], [k][n])
-//   so a fragment read is one conflict-free ds_read_b32 per MFMA operand; the
-//   LDS image is double-buffered and the next tile's global loads are issued
-//   before the current tile's 32 MFMAs, one barrier per k-step.
+//   so a fragment read is one conflict-free ds_read_b32 per MFMA operand. Three
+//   tiles are in flight per block: LDS buffer `cur` (being multiplied), the other
+//   LDS buffer (being written from registers during the first MFMA steps) and the
+//   registers (global loads of tile k+2 issued in step 2); fragment reads run one
+//   step ahead in a register double buffer; one barrier per k-step.
 //   Workgroup ids are remapped so the 8 XCDs each own a contiguous band of
 //   output tiles (per-XCD L2 locality on the shared A row panel).
 // other dtypes / ragged or unaligned shapes: guarded edge variant of the same
@@ -116,34 +118,50 @@ __global__ void __launch_bounds__(256) k_gemm_f32_mfma(GemmArgs g) {
   f32x4 ra[BM * BK / 1024], rb[BN * BK / 1024];
   const int64_t nk = (g.K + BK - 1) / BK;
   // A tile rows = m (row stride a_ms), B tile rows = n (row stride b_ns)
+  // Pipeline: LDS buffer `cur` holds tile kt, registers hold tile kt+1 (landed), and
+  // inside the MFMA stream of tile kt the wave (step 0/1) writes tile kt+1 to the
+  // other LDS buffer and (step 2) issues the global loads of tile kt+2 - so staging
+  // costs no MFMA time of its own and the loads have ~6 steps (>3000 cycles) to land.
   load_tile<BM, BK, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, 0, g.M, g.K, ra);
   load_tile<BN, BK, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, 0, g.N, g.K, rb);
   store_tile<BM, BK, A_KC>(As[0], ra);
   store_tile<BN, BK, B_KC>(Bs[0], rb);
+  if (nk > 1) {
+    load_tile<BM, BK, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, BK, g.M, g.K, ra);
+    load_tile<BN, BK, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, BK, g.N, g.K, rb);
+  }
   __syncthreads();
 
   int cur = 0;
   for (int64_t kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) {
-      load_tile<BM, BK, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 1) * BK, g.M, g.K, ra);
-      load_tile<BN, BK, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 1) * BK, g.N, g.K, rb);
-    }
+    const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
+    float fa[2][WTM], fb[2][WTN];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) fa[0][i] = As[cur][h][wm * (WTM * 32) + i * 32 + l32];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) fb[0][j] = Bs[cur][h][wn * (WTN * 32) + j * 32 + l32];
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float a[WTM], b[WTN];
+      const int c = (kk >> 1) & 1;
+      if (kk + 2 < BK) {  // fragment reads one step ahead (register double buffer)
 #pragma unroll
-      for (int i = 0; i < WTM; ++i) a[i] = As[cur][kk + h][wm * (WTM * 32) + i * 32 + l32];
+        for (int i = 0; i < WTM; ++i) fa[c ^ 1][i] = As[cur][kk + 2 + h][wm * (WTM * 32) + i * 32 + l32];
 #pragma unroll
-      for (int j = 0; j < WTN; ++j) b[j] = Bs[cur][kk + h][wn * (WTN * 32) + j * 32 + l32];
+        for (int j = 0; j < WTN; ++j) fb[c ^ 1][j] = Bs[cur][kk + 2 + h][wn * (WTN * 32) + j * 32 + l32];
+      }
+      if (kk == 0 && more) store_tile<BM, BK, A_KC>(As[cur ^ 1], ra);
+      if (kk == 2 && more) store_tile<BN, BK, B_KC>(Bs[cur ^ 1], rb);
+      if (kk == 4 && more2) {
+        load_tile<BM, BK, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 2) * BK, g.M, g.K, ra);
+        load_tile<BN, BK, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 2) * BK, g.N, g.K, rb);
+      }
+      // pin the order: staging and prefetch are issued ahead of this step's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      store_tile<BM, BK, A_KC>(As[cur ^ 1], ra);
-      store_tile<BN, BK, B_KC>(Bs[cur ^ 1], rb);
+        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     cur ^= 1;
