@@ -85,6 +85,20 @@ class KernelTimer:
         return out
 
 
+def load_pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
+def pmc_mean(pmc, prefix):
+    vals = [v["hbm_bytes_per_launch"] for k, v in pmc.get("kernels", {}).items() if k.startswith(prefix)]
+    return sum(vals) / len(vals) if vals else None
+
+
 def cpu_baseline(workload, size):
     """The oracle (NumPy table + same tape) on the host cores: bounded sample."""
     from minidiff_amd.tape import build_engine
@@ -230,6 +244,7 @@ def main():
         scaling = "weak"
 
     roofline = None
+    pmc = load_pmc_traffic()
     if args.workload in ("cfg2", "cfg4", "cfg5"):
         durs = kernel_ms.get("matmul", [])
         n_gemm = {"cfg2": 3, "cfg4": 2, "cfg5": 5}[args.workload]
@@ -237,20 +252,30 @@ def main():
         if durs:
             avg = sum(durs) / len(durs)
             ach = flop_per_launch / (avg * 1e-3) / 1e12
+            traffic = pmc_mean(pmc, "k_gemm_f32_mfma") if args.workload == "cfg2" and not args.size else None
             roofline = {"bound": "mfma", "kernel": "k_gemm_f32_mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                        "launches": len(durs), "avg_launch_ms": avg, "flop_per_launch": flop_per_launch}
+                        "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                        "traffic_source": pmc.get("_source") if traffic else None,
+                        "launches": len(durs), "avg_launch_ms": avg, "flop_per_launch": flop_per_launch,
+                        "algorithmic_bytes_per_launch": 3 * 4 * (args.size or 4096) ** 2 if args.workload == "cfg2" else None}
     else:
+        # dominant kernel of the eager chain: the f32 multiply (6 of the 11 launches per sweep:
+        # five read 2 x 4N and write 4N, the scaled stride-0 seed only writes 4N -> 64N bytes per sweep)
         n = state["rows"]
-        per_call = {"sin": 8 * n, "cos": 8 * n, "multiply": None, "power": 8 * n, "sum": 4 * n}
-        tot_ms = sum(sum(v) for v in kernel_ms.values())
-        tot_bytes = state["bytes"] * args.steps
-        if tot_ms > 0:
-            ach = tot_bytes / (tot_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_unary_fast/k_binary_fast/k_reduce_rows (11 launches per sweep)",
-                        "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-                        "per_kernel_ms": {k: sum(v) / len(v) for k, v in kernel_ms.items()}}
-        del per_call
+        durs = kernel_ms.get("multiply", [])
+        if durs:
+            avg = sum(durs) / len(durs)
+            bytes_per_launch = 64 * n / 6
+            ach = bytes_per_launch / (avg * 1e-3) / 1e9
+            tot_ms = sum(sum(v) for v in kernel_ms.values())
+            traffic = pmc_mean(pmc, "k_binary_fast<BMul, float, float, float, float>") if not args.size else None
+            roofline = {"bound": "hbm", "kernel": "k_binary_fast<BMul,f32>", "achieved": ach, "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                        "traffic_source": pmc.get("_source") if traffic else None,
+                        "launches": len(durs), "avg_launch_ms": avg, "algorithmic_bytes_per_launch": bytes_per_launch,
+                        "whole_sweep": {"algorithmic_bytes": state["bytes"], "kernel_ms": tot_ms / args.steps,
+                                        "GB/s": state["bytes"] * args.steps / (tot_ms * 1e-3) / 1e9,
+                                        "per_kernel_ms": {k: sum(v) / len(v) for k, v in kernel_ms.items()}}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
