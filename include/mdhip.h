@@ -214,6 +214,42 @@ int mdhip_gather(const mdhip_index_plan *plan, const void *src, int dtype,
 int mdhip_scatter(const mdhip_index_plan *plan, void *dst, int dtype,
                   const mdhip_array *val, int mode);
 
+/* ======================= fused expressions (opt-in lazy mode) ============== */
+/* One pass over HBM for a whole elementwise expression, optionally ending in a
+ * reduction (the "fused elementwise + reduce-to-shape backward" of the north
+ * star). The caller (minidiff_amd/lazy.py) records chains of
+ * backend calls instead of launching them and hands over a POSTFIX program that
+ * a fixed interpreter kernel evaluates per element on a 4-deep register stack:
+ * no runtime compilation. Values are held in `compute_dtype` (F32 or F64);
+ * bool values travel as 0/1. Every operator applies the same functor as the
+ * eager kernel (csrc/md_ops.h), so per-element results are identical. */
+#define MDHIP_VM_MAX_INSTR 48
+#define MDHIP_VM_MAX_LEAVES 8
+#define MDHIP_VM_MAX_CONSTS 16
+#define MDHIP_VM_STACK 4
+enum {
+  MDHIP_VM_PUSH_LEAF = 0, /* arg = leaf index */
+  MDHIP_VM_PUSH_CONST,    /* arg = const index */
+  MDHIP_VM_UNARY,         /* arg = MDHIP_U_* : s0 = f(s0) */
+  MDHIP_VM_BINARY,        /* arg = MDHIP_B_* : s0 = f(s1, s0), pop */
+  MDHIP_VM_WHERE          /* s0 = s2 ? s1 : s0, pop 2 */
+};
+typedef struct mdhip_vm_program {
+  int32_t n_instr, n_leaves, n_consts, compute_dtype;
+  uint8_t kind[MDHIP_VM_MAX_INSTR];
+  uint8_t arg[MDHIP_VM_MAX_INSTR];
+  double consts[MDHIP_VM_MAX_CONSTS];
+  mdhip_array leaves[MDHIP_VM_MAX_LEAVES]; /* each broadcast to out's shape (stride 0 on broadcast axes) */
+} mdhip_vm_program;
+/* out[...] = program(...)  (out dtype: compute_dtype, or BOOL for a 0/1 result) */
+int mdhip_vm_eval(const mdhip_vm_program *prog, const mdhip_array *out);
+/* out = reduce(program) with reduce_op in {SUM, PROD, MAX, MIN}. `shape` is the
+ * program's shape (leaves are broadcast to it); supported forms: all axes reduced,
+ * or a 2-D program reduced over axis 0 (reduce-to-shape of a row broadcast).
+ * Anything else returns MDHIP_EVALUE and the caller materialises first. */
+int mdhip_vm_reduce(const mdhip_vm_program *prog, int reduce_op, const mdhip_array *shape_like,
+                    const mdhip_array *out, uint32_t axis_mask);
+
 /* ======================= data-parallel (RCCL over xGMI) =================== */
 /* One communicator per process (one process per GPU). uid is the 128-byte
  * ncclUniqueId produced on rank 0 and distributed by the launcher. */

@@ -62,6 +62,22 @@ class IndexPlan(C.Structure):
     ]
 
 
+VM_MAX_INSTR, VM_MAX_LEAVES, VM_MAX_CONSTS = 48, 8, 16
+
+
+class VmProgram(C.Structure):
+    _fields_ = [
+        ("n_instr", C.c_int32),
+        ("n_leaves", C.c_int32),
+        ("n_consts", C.c_int32),
+        ("compute_dtype", C.c_int32),
+        ("kind", C.c_uint8 * VM_MAX_INSTR),
+        ("arg", C.c_uint8 * VM_MAX_INSTR),
+        ("consts", C.c_double * VM_MAX_CONSTS),
+        ("leaves", ArrayDesc * VM_MAX_LEAVES),
+    ]
+
+
 _EXC = {1: ValueError, 2: TypeError, 3: IndexError, 4: MemoryError, 5: RuntimeError}
 
 _P = C.POINTER
@@ -89,6 +105,8 @@ _PROTOTYPES = {
     "mdhip_matmul": [_P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc)],
     "mdhip_gather": [_P(IndexPlan), C.c_void_p, C.c_int, _P(ArrayDesc)],
     "mdhip_scatter": [_P(IndexPlan), C.c_void_p, C.c_int, _P(ArrayDesc), C.c_int],
+    "mdhip_vm_eval": [_P(VmProgram), _P(ArrayDesc)],
+    "mdhip_vm_reduce": [_P(VmProgram), C.c_int, _P(ArrayDesc), _P(ArrayDesc), C.c_uint32],
     "mdhip_comm_get_unique_id": [_P(C.c_uint8)],
     "mdhip_comm_init": [C.c_int, C.c_int, _P(C.c_uint8)],
     "mdhip_comm_allreduce_sum": [C.c_void_p, C.c_size_t, C.c_int],

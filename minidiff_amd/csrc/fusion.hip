@@ -1,0 +1,380 @@
+// fusion.hip — one-pass evaluation of recorded elementwise expressions, with an
+// optional reduction epilogue (mdhip_vm_eval / mdhip_vm_reduce in include/mdhip.h).
+//
+// What it replaces: the eager tape launches one kernel per backend call, so the
+// backward of a chain such as sum((sin(x)*y)**2) streams every intermediate through
+// HBM (100*N bytes for cfg3) and the bias gradient of cfg4 first
+// writes g*mask (128 MiB) and then column-sums it. Here the chain is a postfix
+// program interpreted per element (csrc/md_vm.h) — the leaves are read once, the
+// result is written (or reduced) once: HBM-bound at the *fused* byte count.
+//
+// Kernels (all wave-uniform control flow; 4 elements per lane on the vector path):
+//   k_vm_eval_fast     (rows, inner) geometry: leaves contiguous / row- or column-
+//                      broadcast / stride-0, 16-B loads+stores
+//   k_vm_eval_generic  any <=8-D strides, one element per lane
+//   k_vm_reduce_all    full reduction of the program's value (grid-strided sweep,
+//                      block partials + finishing block) — fused "...sum()"
+//   k_vm_reduce_cols   2-D program reduced over rows: lane owns 4 columns, rows
+//                      split over gridDim.y — fused reduce-to-shape (bias gradient)
+// Reductions are deterministic (no atomics).
+#include "md_hip.h"
+#include "md_vm.h"
+
+extern "C" int mdhip_alloc(size_t, void **);
+extern "C" int mdhip_free(void *);
+
+namespace {
+
+template <class T> struct FastLoader {
+  const MdVmDev &P;
+  int64_t row, c;
+  __device__ __forceinline__ void operator()(int l, T (&d)[4]) const {
+    const MdVmLeaf &L = P.leaf[l];
+    const int64_t base = row * L.os;
+    if (L.is) {
+      switch (L.dtype) {
+        case MDHIP_F32: { MdVec<float, 4> v = *reinterpret_cast<const MdVec<float, 4> *>((const float *)L.p + base + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[j] = (T)v.v[j]; } break;
+        case MDHIP_F64: { MdVec<double, 4> v = *reinterpret_cast<const MdVec<double, 4> *>((const double *)L.p + base + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[j] = (T)v.v[j]; } break;
+        case MDHIP_BOOL: { MdVec<uint8_t, 4> v = *reinterpret_cast<const MdVec<uint8_t, 4> *>((const uint8_t *)L.p + base + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[j] = (T)(v.v[j] != 0); } break;
+        case MDHIP_I32: { MdVec<int32_t, 4> v = *reinterpret_cast<const MdVec<int32_t, 4> *>((const int32_t *)L.p + base + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[j] = (T)v.v[j]; } break;
+        default: { MdVec<int64_t, 4> v = *reinterpret_cast<const MdVec<int64_t, 4> *>((const int64_t *)L.p + base + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[j] = (T)v.v[j]; } break;
+      }
+    } else {
+      const T s = md_load<T>(L.p, L.dtype, base);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = s;
+    }
+  }
+};
+template <class T> struct ScalarLoader {  // one element: leaf offsets precomputed by the caller
+  const MdVmDev &P;
+  const int64_t *offs;
+  __device__ __forceinline__ void operator()(int l, T (&d)[1]) const { d[0] = md_load<T>(P.leaf[l].p, P.leaf[l].dtype, offs[l]); }
+};
+template <class T> struct FastLoader1 {  // single element on the fast geometry (tails)
+  const MdVmDev &P;
+  int64_t row, c;
+  __device__ __forceinline__ void operator()(int l, T (&d)[1]) const {
+    const MdVmLeaf &L = P.leaf[l];
+    d[0] = md_load<T>(L.p, L.dtype, row * L.os + (L.is ? c : 0));
+  }
+};
+
+__device__ __forceinline__ void vm_row_col(int64_t v, int64_t nv, int64_t rows, int64_t &row, int64_t &cv) {
+  if (rows == 1) { row = 0; cv = v; }
+  else if ((uint64_t)v < 0x100000000ull && (uint64_t)nv < 0x100000000ull) {
+    uint32_t q = (uint32_t)v / (uint32_t)nv;
+    row = q; cv = (uint32_t)v - q * (uint32_t)nv;
+  } else { row = v / nv; cv = v - row * nv; }
+}
+
+template <class T, class To>
+__global__ void __launch_bounds__(MD_BLOCK) k_vm_eval_fast(MdVmDev P, To *out, int64_t rows, int64_t inner) {
+  const int64_t nv = inner >> 2, total = rows * nv;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t v = gid; v < total; v += gs) {
+    int64_t row, cv;
+    vm_row_col(v, nv, rows, row, cv);
+    FastLoader<T> ld{P, row, cv << 2};
+    T r[4];
+    md_vm_run<T, 4>(P.n_instr, P.kind, P.arg, P.consts, ld, r);
+    MdVec<To, 4> o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = md_cast<To>(r[j]);
+    *reinterpret_cast<MdVec<To, 4> *>(out + row * inner + (cv << 2)) = o;
+  }
+  if (rows == 1) {
+    const int64_t t0 = nv << 2;
+    if (gid < inner - t0) {
+      FastLoader1<T> ld{P, 0, t0 + gid};
+      T r[1];
+      md_vm_run<T, 1>(P.n_instr, P.kind, P.arg, P.consts, ld, r);
+      out[t0 + gid] = md_cast<To>(r[0]);
+    }
+  }
+}
+
+template <class T, class To>
+__global__ void __launch_bounds__(MD_BLOCK) k_vm_eval_generic(MdVmDev P, MdVmIter it, To *out) {
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < it.total; i += gs) {
+    int64_t offs[MDHIP_VM_MAX_LEAVES + 1];
+    for (int l = 0; l <= MDHIP_VM_MAX_LEAVES; ++l) offs[l] = 0;
+    int64_t lin = i;
+    for (int d = it.ndim - 1; d >= 0; --d) {
+      const int64_t e = it.shape[d], q = lin / e, r = lin - q * e;
+      lin = q;
+      for (int l = 0; l < P.n_leaves; ++l) offs[l] += r * it.strides[l][d];
+      offs[MDHIP_VM_MAX_LEAVES] += r * it.strides[MDHIP_VM_MAX_LEAVES][d];
+    }
+    ScalarLoader<T> ld{P, offs};
+    T r[1];
+    md_vm_run<T, 1>(P.n_instr, P.kind, P.arg, P.consts, ld, r);
+    out[offs[MDHIP_VM_MAX_LEAVES]] = md_cast<To>(r[0]);
+  }
+}
+
+// ------------------------------------------------------------------ reductions ----
+template <class R, class T> __device__ __forceinline__ T vm_block_reduce(T v, T *smem) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = R::combine(v, md_shfl_down(v, d));
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  if (w == 0) {
+    v = lane < nw ? smem[lane] : R::template identity<T>();
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) v = R::combine(v, md_shfl_down(v, d));
+  }
+  return v;
+}
+
+template <class R, class T>
+__global__ void __launch_bounds__(MD_BLOCK) k_vm_reduce_all(MdVmDev P, int64_t rows, int64_t inner, T *partial) {
+  __shared__ T smem[MD_BLOCK / 64];
+  const int64_t nv = inner >> 2, total = rows * nv;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gs = (int64_t)gridDim.x * blockDim.x;
+  T a[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = R::template identity<T>();
+  for (int64_t v = gid; v < total; v += gs) {
+    int64_t row, cv;
+    vm_row_col(v, nv, rows, row, cv);
+    FastLoader<T> ld{P, row, cv << 2};
+    T r[4];
+    md_vm_run<T, 4>(P.n_instr, P.kind, P.arg, P.consts, ld, r);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = R::combine(a[j], r[j]);
+  }
+  T acc = R::combine(R::combine(a[0], a[1]), R::combine(a[2], a[3]));
+  if (rows == 1) {
+    const int64_t t0 = nv << 2;
+    if (gid < inner - t0) {
+      FastLoader1<T> ld{P, 0, t0 + gid};
+      T r[1];
+      md_vm_run<T, 1>(P.n_instr, P.kind, P.arg, P.consts, ld, r);
+      acc = R::combine(acc, r[0]);
+    }
+  }
+  acc = vm_block_reduce<R>(acc, smem);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+template <class R, class T>
+__global__ void __launch_bounds__(MD_BLOCK) k_vm_finish_all(const T *partial, int64_t n, T *out) {
+  __shared__ T smem[MD_BLOCK / 64];
+  T acc = R::template identity<T>();
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc = R::combine(acc, partial[i]);
+  acc = vm_block_reduce<R>(acc, smem);
+  if (threadIdx.x == 0) out[0] = acc;
+}
+
+// 2-D program [n_red rows][n_out cols] reduced over rows; lane owns 4 columns.
+template <class R, class T, bool FINAL>
+__global__ void __launch_bounds__(MD_BLOCK) k_vm_reduce_cols(MdVmDev P, int64_t n_out, int64_t n_red, int64_t chunk, T *dst) {
+  __shared__ T smem[3][64][4];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t col = ((int64_t)blockIdx.x * 64 + cx) * 4;
+  const int64_t s = blockIdx.y, r0 = s * chunk;
+  int64_t r1 = r0 + chunk;
+  if (r1 > n_red) r1 = n_red;
+  T a[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[u][j] = R::template identity<T>();
+  if (col < n_out) {
+    int64_t r = r0 + ry;
+    for (; r + 4 < r1; r += 8) {
+      T v0[4], v1[4];
+      FastLoader<T> l0{P, r, col}, l1{P, r + 4, col};
+      md_vm_run<T, 4>(P.n_instr, P.kind, P.arg, P.consts, l0, v0);
+      md_vm_run<T, 4>(P.n_instr, P.kind, P.arg, P.consts, l1, v1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[0][j] = R::combine(a[0][j], v0[j]); a[1][j] = R::combine(a[1][j], v1[j]); }
+    }
+    for (; r < r1; r += 4) {
+      T v0[4];
+      FastLoader<T> l0{P, r, col};
+      md_vm_run<T, 4>(P.n_instr, P.kind, P.arg, P.consts, l0, v0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[0][j] = R::combine(a[0][j], v0[j]);
+    }
+  }
+  T tot[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) tot[j] = R::combine(a[0][j], a[1][j]);
+  if (ry > 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) smem[ry - 1][cx][j] = tot[j];
+  }
+  __syncthreads();
+  if (ry == 0 && col < n_out) {
+    MdVec<T, 4> o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = R::combine(R::combine(tot[j], smem[0][cx][j]), R::combine(smem[1][cx][j], smem[2][cx][j]));
+    T *d = FINAL ? dst + col : dst + s * n_out + col;
+    *reinterpret_cast<MdVec<T, 4> *>(d) = o;
+  }
+}
+
+// ------------------------------------------------------------------------ host ----
+static void to_dev(const mdhip_vm_program *pr, MdVmDev *D) {
+  memset(D, 0, sizeof *D);
+  D->n_instr = pr->n_instr;
+  D->n_leaves = pr->n_leaves;
+  memcpy(D->kind, pr->kind, sizeof D->kind);
+  memcpy(D->arg, pr->arg, sizeof D->arg);
+  memcpy(D->consts, pr->consts, sizeof D->consts);
+  for (int l = 0; l < pr->n_leaves; ++l) {
+    D->leaf[l].p = pr->leaves[l].data;
+    D->leaf[l].dtype = pr->leaves[l].dtype;
+  }
+}
+static bool al_for(const void *p, int dtype) {
+  const uintptr_t al = md_dtype_size(dtype) * 4 > 16 ? 16 : md_dtype_size(dtype) * 4;
+  return ((uintptr_t)p % al) == 0;
+}
+// (rows, inner) geometry usable by the vector kernels? fills leaf os/is.
+static bool fast_geometry(const MdVmIter &it, int n_leaves, const mdhip_vm_program *pr, bool out_contig_required, MdVmDev *D,
+                          int64_t *rows, int64_t *inner) {
+  if (it.ndim < 1 || it.ndim > 2) return false;
+  *inner = it.shape[it.ndim - 1];
+  *rows = it.ndim == 2 ? it.shape[0] : 1;
+  if (*rows > 1 && (*inner & 3)) return false;
+  const int O = MDHIP_VM_MAX_LEAVES;
+  if (out_contig_required) {
+    if (it.strides[O][it.ndim - 1] != 1) return false;
+    if (it.ndim == 2 && it.strides[O][0] != *inner) return false;
+  }
+  for (int l = 0; l < n_leaves; ++l) {
+    const int64_t is = it.strides[l][it.ndim - 1], os = it.ndim == 2 ? it.strides[l][0] : 0;
+    if (is != 0 && is != 1) return false;
+    if (is == 1) {
+      if (!al_for(pr->leaves[l].data, pr->leaves[l].dtype)) return false;
+      if (*rows > 1 && (os & 3)) return false;
+    }
+    D->leaf[l].os = os;
+    D->leaf[l].is = (int32_t)is;
+  }
+  return true;
+}
+
+template <class T> static int eval_typed(const mdhip_vm_program *pr, const mdhip_array *out) {
+  MdVmIter it;
+  MD_TRY(md_vm_build_iter(&it, pr, out, out));
+  if (it.total == 0) return MDHIP_OK;
+  MdVmDev D;
+  to_dev(pr, &D);
+  hipStream_t st = md_stream();
+  int64_t rows, inner;
+  const bool to_bool = out->dtype == MDHIP_BOOL;
+  if (fast_geometry(it, pr->n_leaves, pr, true, &D, &rows, &inner) && al_for(out->data, out->dtype)) {
+    const int64_t work = rows * (inner >> 2) + (rows == 1 ? 4 : 0);
+    if (to_bool) k_vm_eval_fast<T, b8><<<md_grid_for(work), MD_BLOCK, 0, st>>>(D, (b8 *)out->data, rows, inner);
+    else k_vm_eval_fast<T, T><<<md_grid_for(work), MD_BLOCK, 0, st>>>(D, (T *)out->data, rows, inner);
+    return MD_LAUNCH_CHECK("vm_eval(fast)");
+  }
+  if (to_bool) k_vm_eval_generic<T, b8><<<md_grid_for(it.total), MD_BLOCK, 0, st>>>(D, it, (b8 *)out->data);
+  else k_vm_eval_generic<T, T><<<md_grid_for(it.total), MD_BLOCK, 0, st>>>(D, it, (T *)out->data);
+  return MD_LAUNCH_CHECK("vm_eval(generic)");
+}
+
+static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+template <class R, class T>
+static int reduce_typed(const mdhip_vm_program *pr, const mdhip_array *shape_like, const mdhip_array *out, uint32_t mask) {
+  const int nd = shape_like->ndim;
+  const uint32_t all = nd ? ((1u << nd) - 1u) : 0u;
+  MdVmIter it;
+  MD_TRY(md_vm_build_iter(&it, pr, shape_like, nullptr));
+  if (it.total == 0) return md_fail(MDHIP_EVALUE, "vm_reduce: empty operand");
+  MdVmDev D;
+  to_dev(pr, &D);
+  hipStream_t st = md_stream();
+  int64_t rows, inner;
+  if (!fast_geometry(it, pr->n_leaves, pr, false, &D, &rows, &inner)) return md_fail(MDHIP_EVALUE, "vm_reduce: geometry not supported");
+  if (((uintptr_t)out->data & 15) != 0) return md_fail(MDHIP_EVALUE, "vm_reduce: unaligned output");
+  if (mask == all) {
+    const int64_t work = rows * (inner >> 2) + (rows == 1 ? 4 : 0);
+    const int grid = md_grid_for(work);
+    void *partial = nullptr;
+    MD_TRY(mdhip_alloc((size_t)grid * sizeof(T), &partial));
+    k_vm_reduce_all<R, T><<<grid, MD_BLOCK, 0, st>>>(D, rows, inner, (T *)partial);
+    k_vm_finish_all<R, T><<<1, MD_BLOCK, 0, st>>>((const T *)partial, grid, (T *)out->data);
+    int rc = MD_LAUNCH_CHECK("vm_reduce(all)");
+    mdhip_free(partial);
+    return rc;
+  }
+  // reduce over axis 0 of a 2-D program that did NOT collapse to 1-D
+  if (nd == 2 && mask == 1u && it.ndim == 2 && shape_like->shape[0] == rows && shape_like->shape[1] == inner) {
+    const int64_t n_out = inner, n_red = rows;
+    const int64_t bx = ceil_div(n_out, 256);
+    int64_t splits = 1024 / bx;
+    if (splits > n_red / 32) splits = n_red / 32;
+    if (splits > 65535) splits = 65535;
+    if (splits < 1) splits = 1;
+    const int64_t chunk = ceil_div(ceil_div(n_red, splits), 8) * 8;
+    splits = ceil_div(n_red, chunk);
+    if (splits == 1) {
+      k_vm_reduce_cols<R, T, true><<<dim3((unsigned)bx, 1), MD_BLOCK, 0, st>>>(D, n_out, n_red, chunk, (T *)out->data);
+      return MD_LAUNCH_CHECK("vm_reduce(cols)");
+    }
+    void *partial = nullptr;
+    MD_TRY(mdhip_alloc((size_t)(splits * n_out) * sizeof(T), &partial));
+    k_vm_reduce_cols<R, T, false><<<dim3((unsigned)bx, (unsigned)splits), MD_BLOCK, 0, st>>>(D, n_out, n_red, chunk, (T *)partial);
+    // second pass: a one-instruction program over the partial buffer
+    MdVmDev F;
+    memset(&F, 0, sizeof F);
+    F.n_instr = 1; F.n_leaves = 1;
+    F.kind[0] = MDHIP_VM_PUSH_LEAF; F.arg[0] = 0;
+    F.leaf[0].p = partial; F.leaf[0].os = n_out; F.leaf[0].is = 1; F.leaf[0].dtype = md_dtype_of<T>::value;
+    const int64_t chunk2 = ceil_div(splits, 8) * 8;
+    k_vm_reduce_cols<R, T, true><<<dim3((unsigned)bx, 1), MD_BLOCK, 0, st>>>(F, n_out, splits, chunk2, (T *)out->data);
+    int rc = MD_LAUNCH_CHECK("vm_reduce(cols,split)");
+    mdhip_free(partial);
+    return rc;
+  }
+  return md_fail(MDHIP_EVALUE, "vm_reduce: only full reductions and axis-0 reductions of 2-D programs are fused");
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdhip_vm_eval(const mdhip_vm_program *pr, const mdhip_array *out) {
+  MD_TRY(md_vm_check(pr));
+  MD_TRY(md_check_array(out, "vm out"));
+  if (out->dtype != pr->compute_dtype && out->dtype != MDHIP_BOOL)
+    return md_fail(MDHIP_ETYPE, "vm_eval: out dtype must be the compute dtype or bool");
+  return pr->compute_dtype == MDHIP_F32 ? eval_typed<float>(pr, out) : eval_typed<double>(pr, out);
+}
+
+int mdhip_vm_reduce(const mdhip_vm_program *pr, int op, const mdhip_array *shape_like, const mdhip_array *out, uint32_t mask) {
+  MD_TRY(md_vm_check(pr));
+  MD_TRY(md_check_array(shape_like, "vm shape"));
+  MD_TRY(md_check_array(out, "vm out"));
+  if (out->dtype != pr->compute_dtype) return md_fail(MDHIP_ETYPE, "vm_reduce: out dtype must be the compute dtype");
+#define MD_VMR(R)                                                                                         \
+  return pr->compute_dtype == MDHIP_F32 ? reduce_typed<R, float>(pr, shape_like, out, mask)               \
+                                        : reduce_typed<R, double>(pr, shape_like, out, mask)
+  switch (op) {
+    case MDHIP_R_SUM: MD_VMR(RSum);
+    case MDHIP_R_PROD: MD_VMR(RProd);
+    case MDHIP_R_MAX: MD_VMR(RMax);
+    case MDHIP_R_MIN: MD_VMR(RMin);
+  }
+#undef MD_VMR
+  return md_fail(MDHIP_EVALUE, "vm_reduce: reduce op %d is not fused", op);
+}
+
+}  // extern "C"

@@ -50,6 +50,8 @@ class RcclComm:
 
         if not arr.is_c_contiguous:
             raise ValueError("allreduce needs a contiguous device buffer")
+        nd.materialize(arr)
+        nd._before_write(arr)
         self.lib.comm_allreduce_sum(arr.ptr, arr.size, nd.dtype_code(arr.dtype))
 
     def close(self):

@@ -226,6 +226,7 @@ class HipBackendTable:
 
     # ---- extras the harness uses (not part of the reference table) -----------
     _synchronize = staticmethod(nd.synchronize)
+    _materialize = staticmethod(nd.materialize)
 
 
 def public_names() -> list:

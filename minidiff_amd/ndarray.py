@@ -18,6 +18,8 @@ import builtins as _bi
 import ctypes as C
 import math
 import operator
+import os
+import weakref
 from builtins import bool as py_bool
 
 # this module defines sum/max/min/any/all with NumPy meaning; keep the builtins
@@ -26,7 +28,27 @@ builtins_min, builtins_max, builtins_sum, builtins_any, builtins_all = _bi.min, 
 import numpy as np
 
 from . import _capi
+from . import lazy as _lz
 from ._capi import ArrayDesc, IndexPlan, MAX_NDIM
+
+# Lazy fusion of elementwise chains (minidiff_amd/lazy.py) is opt-in; eager —
+# one kernel per backend call, the reference's execution model — is the default.
+_LAZY = os.environ.get("MDHIP_LAZY", "0") == "1"
+
+
+def set_lazy(flag: bool) -> bool:
+    """Switch lazy fusion on/off; returns the previous setting."""
+    global _LAZY
+    prev, _LAZY = _LAZY, py_bool(flag)
+    return prev
+
+
+def lazy_enabled() -> bool:
+    return _LAZY
+
+
+# launches issued for pending expressions (tests assert that fusion really happened)
+FUSION_STATS = {"vm_eval": 0, "vm_reduce": 0}
 
 _DTYPE_CODES = {
     np.dtype(np.bool_): _capi.BOOL,
@@ -60,9 +82,10 @@ def _lib() -> _capi.Library:
 class _Buffer:
     """Owner of one allocator block; freed when the last view drops it."""
 
-    __slots__ = ("ptr", "nbytes", "_free")
+    __slots__ = ("ptr", "nbytes", "_free", "deps")
 
     def __init__(self, nbytes: int):
+        self.deps = None  # {id: weakref} of pending (lazy) arrays that read this block
         lib = _lib()
         p = C.c_void_p()
         lib.alloc(builtins_max(int(nbytes), 1), C.byref(p))
@@ -124,7 +147,7 @@ def normalize_axes(axis, ndim) -> tuple:
 
 
 class DeviceArray:
-    __slots__ = ("_buf", "_offset", "shape", "_strides", "dtype", "_code", "__weakref__")
+    __slots__ = ("_buf", "_offset", "shape", "_strides", "dtype", "_code", "_expr", "__weakref__")
     __array_priority__ = 1000.0
     __hash__ = None
 
@@ -135,6 +158,38 @@ class DeviceArray:
         self._strides = strides
         self.dtype = dtype
         self._code = code if code >= 0 else dtype_code(dtype)
+        self._expr = None  # pending expression (lazy mode); _buf is None until materialised
+
+    # ---- lazy evaluation -----------------------------------------------------
+    @staticmethod
+    def _pending(expr, shape, dtype) -> "DeviceArray":
+        arr = DeviceArray(None, 0, shape, _c_strides(shape), dtype)
+        arr._expr = expr
+        key = id(arr)
+        for leaf in expr.leaves.values():
+            b = leaf._buf
+            if b.deps is None:
+                b.deps = {}
+            deps = b.deps
+            deps[key] = weakref.ref(arr, lambda _r, k=key, d=deps: d.pop(k, None))  # (arrays are unhashable)
+        return arr
+
+    def _materialize(self):
+        e = self._expr
+        if e is None:
+            return
+        prog, keep = _lz.build_program(e, self.shape)
+        self._buf = _Buffer(_prod(self.shape) * self.dtype.itemsize)
+        self._expr = None
+        if self.size:
+            _lib().vm_eval(prog, self.desc())
+            FUSION_STATS["vm_eval"] += 1
+        del keep
+
+    def materialize(self) -> "DeviceArray":
+        if self._buf is None:
+            self._materialize()
+        return self
 
     # ---- construction -------------------------------------------------------
     @staticmethod
@@ -163,6 +218,8 @@ class DeviceArray:
     # ---- geometry -----------------------------------------------------------
     @property
     def ptr(self) -> int:
+        if self._buf is None:
+            self._materialize()
         return self._buf.ptr + self._offset * self.dtype.itemsize
 
     @property
@@ -200,6 +257,8 @@ class DeviceArray:
 
     @property
     def base(self):
+        if self._buf is None:
+            self._materialize()
         return self._buf
 
     @property
@@ -207,6 +266,8 @@ class DeviceArray:
         return transpose(self)
 
     def _view(self, offset, shape, strides) -> "DeviceArray":
+        if self._buf is None:
+            self._materialize()
         return DeviceArray(self._buf, offset, tuple(shape), tuple(strides), self.dtype, self._code)
 
     def desc(self, shape=None) -> ArrayDesc:
@@ -563,6 +624,52 @@ def _scalar_code(x, loop_dt) -> int:
     return _capi.I64
 
 
+_FLOAT_DT = {np.dtype(np.float32): _capi.F32, np.dtype(np.float64): _capi.F64}
+
+
+def _before_write(arr: "DeviceArray"):
+    """Evaluate every pending expression that still reads `arr`'s block (called by all
+    in-place entry points: lazy results must see the bytes as they were when recorded)."""
+    b = arr._buf
+    if b is not None and b.deps:
+        pending = [r() for r in list(b.deps.values())]
+        b.deps = None
+        for d in pending:
+            if d is not None:
+                d._materialize()
+
+
+def _as_expr(x, cdt):
+    """operand -> expression node of a program computing in float type `cdt`."""
+    if isinstance(x, DeviceArray):
+        e = x._expr
+        if e is not None:
+            if e.cdt == cdt:
+                return e
+            x._materialize()
+        return _lz.leaf(x, cdt)
+    if isinstance(x, np.generic):
+        return _lz.const(x.item(), cdt)
+    return _lz.const(x, cdt)
+
+
+def _lazy_node(kind, code, operands, cdt, shape, odt):
+    """Build a pending result, materialising the largest pending operand(s) while the
+    program would not fit the interpreter."""
+    while True:
+        parts = [_as_expr(x, cdt) for x in operands]
+        e = _lz.combine(kind, code, parts, cdt)
+        if _lz.fits(e):
+            return DeviceArray._pending(e, shape, odt)
+        big = None
+        for x in operands:
+            if isinstance(x, DeviceArray) and x._expr is not None and (big is None or x._expr.n > big._expr.n):
+                big = x
+        if big is None:
+            return None
+        big._materialize()
+
+
 def _binary(ufunc, code, a, b, out=None):
     a = _operand(a)
     b = _operand(b)
@@ -579,12 +686,25 @@ def _binary(ufunc, code, a, b, out=None):
         shape = _broadcast_shapes(a.shape, b.shape)
     else:
         shape = a.shape if a_arr else b.shape
+    if _LAZY and out is None:
+        pcdt = _FLOAT_DT.get(cdt)
+        if pcdt is None and cdt.kind == "b" and code >= _capi.B_LAND:
+            # logical op on bool operands: join the program of a pending operand
+            for x in (a, b):
+                if isinstance(x, DeviceArray) and x._expr is not None:
+                    pcdt = x._expr.cdt
+                    break
+        if pcdt is not None and _prod(shape) > 0:
+            res = _lazy_node(_lz.BINARY, code, (a, b), pcdt, shape, odt)
+            if res is not None:
+                return res
     da = _operand_desc(a, shape, 0 if a_arr else _scalar_code(a, cdt))
     db = _operand_desc(b, shape, 0 if b_arr else _scalar_code(b, cdt))
     if out is None:
         res = DeviceArray.empty(shape, odt)
         _lib().binary(code, da, db, res.desc(), _DTYPE_CODES[cdt])
         return res
+    _before_write(out)
     # in-place: NumPy's same_kind casting rule for the `out=` operand
     if shape != out.shape:
         raise ValueError(f"non-broadcastable output operand with shape {out.shape} doesn't match the broadcast shape {shape}")
@@ -617,6 +737,13 @@ def _unary(ufunc, code, x):
         for dt in loop:
             dtype_code(dt)
         _RESOLVE_CACHE[key] = loop
+    if _LAZY and code != _capi.U_INVERT and x.size > 0:
+        pcdt = _FLOAT_DT.get(loop[0])
+        if pcdt is not None and (loop[1] == loop[0] or loop[1] == np.bool_) and x.dtype.kind in "fb" or \
+                (pcdt is not None and x.dtype.kind == "i" and pcdt == _capi.F64):
+            res = _lazy_node(_lz.UNARY, code, (x,), pcdt, x.shape, loop[1])
+            if res is not None:
+                return res
     res = DeviceArray.empty(x.shape, loop[1])
     _lib().unary(code, x.desc(), res.desc())
     return res
@@ -624,6 +751,7 @@ def _unary(ufunc, code, x):
 
 def _copy_into(dst: DeviceArray, src, shape=None):
     """dst[...] = src with broadcasting and dtype conversion (unary COPY kernel)."""
+    _before_write(dst)
     if isinstance(src, DeviceArray):
         sd = src.desc(dst.shape)
     else:
@@ -638,6 +766,7 @@ def _copy_into(dst: DeviceArray, src, shape=None):
 
 
 def _fill(dst: DeviceArray, value):
+    _before_write(dst)
     if isinstance(value, DeviceArray):
         _copy_into(dst, value)
         return
@@ -725,6 +854,12 @@ def where(condition, x=None, y=None):
     shape = arrs[0].shape
     for v in arrs[1:]:
         shape = _broadcast_shapes(shape, v.shape)
+    if _LAZY and _prod(shape) > 0:
+        pcdt = _FLOAT_DT.get(odt)
+        if pcdt is not None:
+            res = _lazy_node(_lz.WHERE, 0, (c, a, b), pcdt, shape, odt)
+            if res is not None:
+                return res
     res = DeviceArray.empty(shape, odt)
     dc = _operand_desc(c, shape, _capi.I64)
     da = _operand_desc(a, shape, 0 if isinstance(a, DeviceArray) else _scalar_code(a, odt))
@@ -987,11 +1122,47 @@ def _reduce(code, a, axis, keepdims, out_dtype):
     for ax in axes:
         mask |= 1 << ax
     kshape = tuple(1 if (mask >> i) & 1 else n for i, n in enumerate(a.shape))
+    if a._expr is not None:
+        fused = _fused_reduce(code, a, mask, kshape, np.dtype(out_dtype))
+        if fused is not None:
+            if not keepdims:
+                fshape = tuple(n for i, n in enumerate(a.shape) if not (mask >> i) & 1)
+                fused = fused._view(fused._offset, fshape, _c_strides(fshape))
+            return fused
     res = DeviceArray.empty(kshape, out_dtype)
     _lib().reduce(code, a.desc(), res.desc(), mask)
     if not keepdims:
         fshape = tuple(n for i, n in enumerate(a.shape) if not (mask >> i) & 1)
         res = res._view(res._offset, fshape, _c_strides(fshape))
+    return res
+
+
+def _fused_reduce(code, a, mask, kshape, out_dtype):
+    """reduce(pending expression) in one pass: full reductions and the axis-0
+    reduce-to-shape of a 2-D expression; None -> caller materialises and reduces."""
+    e = a._expr
+    if code not in (_capi.R_SUM, _capi.R_PROD, _capi.R_MAX, _capi.R_MIN):
+        return None
+    if _FLOAT_DT.get(out_dtype) != e.cdt or a.dtype != out_dtype or a.size == 0:
+        return None
+    nd = a.ndim
+    full = mask == (1 << nd) - 1
+    cols = nd == 2 and mask == 1 and a.shape[0] > 1 and a.shape[1] > 1 and a.shape[1] % 4 == 0
+    if not (full or cols):
+        return None
+    prog, keep = _lz.build_program(e, a.shape)
+    res = DeviceArray.empty(kshape, out_dtype)
+    shape_like = ArrayDesc()
+    shape_like.dtype = e.cdt
+    shape_like.ndim = nd
+    if nd:
+        shape_like.shape[:nd] = a.shape
+    try:
+        _lib().vm_reduce(prog, code, shape_like, res.desc(), mask)
+    except ValueError:
+        return None
+    FUSION_STATS["vm_reduce"] += 1
+    del keep
     return res
 
 
@@ -1606,6 +1777,7 @@ def getitem(a, key):
 
 
 def _scatter(a: DeviceArray, key, value, mode):
+    _before_write(a)
     entries, has_adv = _parse_key(a, key)
     if not has_adv:
         dst = _basic_view(a, entries)
@@ -1692,6 +1864,7 @@ def put_along_axis(arr, indices, values, axis):
     if not isinstance(arr, DeviceArray):
         raise TypeError("put_along_axis needs a DeviceArray destination")
     indices = asarray(indices)
+    _before_write(arr)
     if axis is None:
         if not arr.is_c_contiguous:
             raise ValueError("put_along_axis(axis=None) needs a contiguous destination")
@@ -1730,6 +1903,13 @@ def unravel_index(indices, shape, **kw):
     i = indices.get() if isinstance(indices, DeviceArray) else indices
     out = np.unravel_index(i, shape, **kw)
     return tuple(asarray(np.asarray(o)) for o in out)
+
+
+def materialize(a):
+    """Force a pending (lazy) array into HBM; a no-op for materialised arrays."""
+    if isinstance(a, DeviceArray) and a._buf is None:
+        a._materialize()
+    return a
 
 
 def synchronize():

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../minidiff_amd/csrc/md_dispatch.h"
+#include "../../minidiff_amd/csrc/md_vm.h"
 
 std::string &md_err_slot() {
   static thread_local std::string s;
@@ -259,6 +260,91 @@ int mdhip_scatter(const mdhip_index_plan *pl, void *dst, int dtype, const mdhip_
     (void)es;
   }
   return MDHIP_OK;
+}
+
+// fused expressions: same interpreter (csrc/md_vm.h), one element at a time
+extern "C++" {
+template <class T> struct HostVmLoader {
+  const mdhip_vm_program *pr;
+  const int64_t *offs;
+  void operator()(int l, T (&d)[1]) const { d[0] = md_load<T>(pr->leaves[l].data, pr->leaves[l].dtype, offs[l]); }
+};
+template <class T> static T host_vm_at(const mdhip_vm_program *pr, const MdVmIter &it, int64_t i, int64_t *out_off) {
+  int64_t offs[MDHIP_VM_MAX_LEAVES + 1] = {0};
+  int64_t lin = i;
+  for (int d = it.ndim - 1; d >= 0; --d) {
+    const int64_t e = it.shape[d], q = lin / e, r = lin - q * e;
+    lin = q;
+    for (int l = 0; l < pr->n_leaves; ++l) offs[l] += r * it.strides[l][d];
+    offs[MDHIP_VM_MAX_LEAVES] += r * it.strides[MDHIP_VM_MAX_LEAVES][d];
+  }
+  HostVmLoader<T> ld{pr, offs};
+  T r[1];
+  md_vm_run<T, 1>(pr->n_instr, pr->kind, pr->arg, pr->consts, ld, r);
+  if (out_off) *out_off = offs[MDHIP_VM_MAX_LEAVES];
+  return r[0];
+}
+template <class T> static int host_vm_eval(const mdhip_vm_program *pr, const mdhip_array *out) {
+  MdVmIter it;
+  MD_TRY(md_vm_build_iter(&it, pr, out, out));
+  for (int64_t i = 0; i < it.total; ++i) {
+    int64_t oo;
+    T v = host_vm_at<T>(pr, it, i, &oo);
+    if (out->dtype == MDHIP_BOOL) ((uint8_t *)out->data)[oo] = (uint8_t)(v != (T)0);
+    else ((T *)out->data)[oo] = v;
+  }
+  return MDHIP_OK;
+}
+template <class R, class T>
+static int host_vm_reduce(const mdhip_vm_program *pr, const mdhip_array *shape_like, const mdhip_array *out, uint32_t mask) {
+  const int nd = shape_like->ndim;
+  const uint32_t all = nd ? ((1u << nd) - 1u) : 0u;
+  // un-collapsed walk so (row, col) stay identifiable
+  mdhip_array fake = *shape_like;
+  MdVmIter it;
+  MD_TRY(md_vm_build_iter(&it, pr, &fake, nullptr));
+  if (it.total == 0) return md_fail(MDHIP_EVALUE, "vm_reduce: empty operand");
+  if (mask == all) {
+    T acc = R::template identity<T>();
+    for (int64_t i = 0; i < it.total; ++i) acc = R::combine(acc, host_vm_at<T>(pr, it, i, nullptr));
+    ((T *)out->data)[0] = acc;
+    return MDHIP_OK;
+  }
+  if (nd == 2 && mask == 1u) {
+    const int64_t rows = shape_like->shape[0], cols = shape_like->shape[1];
+    if (it.ndim != 2 || it.shape[0] != rows || it.shape[1] != cols || (cols & 3))
+      return md_fail(MDHIP_EVALUE, "vm_reduce: geometry not supported");
+    for (int64_t c = 0; c < cols; ++c) {
+      T acc = R::template identity<T>();
+      for (int64_t r = 0; r < rows; ++r) acc = R::combine(acc, host_vm_at<T>(pr, it, r * cols + c, nullptr));
+      ((T *)out->data)[c] = acc;
+    }
+    return MDHIP_OK;
+  }
+  return md_fail(MDHIP_EVALUE, "vm_reduce: only full reductions and axis-0 reductions of 2-D programs are fused");
+}
+}  // extern "C++"
+int mdhip_vm_eval(const mdhip_vm_program *pr, const mdhip_array *out) {
+  MD_TRY(md_vm_check(pr));
+  MD_TRY(md_check_array(out, "vm out"));
+  if (out->dtype != pr->compute_dtype && out->dtype != MDHIP_BOOL)
+    return md_fail(MDHIP_ETYPE, "vm_eval: out dtype must be the compute dtype or bool");
+  return pr->compute_dtype == MDHIP_F32 ? host_vm_eval<float>(pr, out) : host_vm_eval<double>(pr, out);
+}
+int mdhip_vm_reduce(const mdhip_vm_program *pr, int op, const mdhip_array *shape_like, const mdhip_array *out, uint32_t mask) {
+  MD_TRY(md_vm_check(pr));
+  MD_TRY(md_check_array(shape_like, "vm shape"));
+  MD_TRY(md_check_array(out, "vm out"));
+  if (out->dtype != pr->compute_dtype) return md_fail(MDHIP_ETYPE, "vm_reduce: out dtype must be the compute dtype");
+#define MD_VMR(R) return pr->compute_dtype == MDHIP_F32 ? host_vm_reduce<R, float>(pr, shape_like, out, mask) : host_vm_reduce<R, double>(pr, shape_like, out, mask)
+  switch (op) {
+    case MDHIP_R_SUM: MD_VMR(RSum);
+    case MDHIP_R_PROD: MD_VMR(RProd);
+    case MDHIP_R_MAX: MD_VMR(RMax);
+    case MDHIP_R_MIN: MD_VMR(RMin);
+  }
+#undef MD_VMR
+  return md_fail(MDHIP_EVALUE, "vm_reduce: reduce op %d is not fused", op);
 }
 
 // data-parallel entry points: the double has no collective; world size 1 only.

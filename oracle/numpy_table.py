@@ -73,6 +73,7 @@ def _build():
         nan=np.nan,
         as_numpy=staticmethod(lambda a: a),
         _synchronize=staticmethod(lambda: None),
+        _materialize=staticmethod(lambda a: a),
     )
     return type("NumpyOracleTable", (), ns)
 

@@ -1,0 +1,144 @@
+"""Opt-in lazy fusion (minidiff_amd/lazy.py + mdhip_vm_eval / mdhip_vm_reduce):
+fused results equal the eager ones (same per-element functors), pending
+expressions survive in-place writes to their leaves, programs that outgrow the
+interpreter are split, and the fused launches really replace the eager ones."""
+import numpy as np
+import pytest
+
+gpu = pytest.mark.gpu
+
+
+@pytest.fixture
+def lazy_nd(lib):
+    from minidiff_amd import ndarray as nd
+    prev = nd.set_lazy(True)
+    yield nd
+    nd.set_lazy(prev)
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-30)
+    assert np.abs(a - b).max() / scale <= tol, np.abs(a - b).max() / scale
+
+
+def _chain(nd, on_gpu, want_gpu):
+    if want_gpu != on_gpu:
+        pytest.skip("other twin")
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((64, 256)).astype(np.float32)
+    y = rng.standard_normal((64, 256)).astype(np.float32)
+    b = rng.standard_normal((256,)).astype(np.float32)
+    dx, dy, db = nd.asarray(x), nd.asarray(y), nd.asarray(b)
+    before = dict(nd.FUSION_STATS)
+    e = nd.multiply(nd.power(nd.multiply(nd.sin(dx), dy), 2), nd.cos(dx))
+    e = nd.where(nd.greater(nd.add(e, db), 0), e, 0.5)
+    assert e._expr is not None and e._buf is None, "chain should still be pending"
+    exp = np.where((np.sin(x) * y) ** 2 * np.cos(x) + b > 0, (np.sin(x) * y) ** 2 * np.cos(x), np.float32(0.5))
+    tot = nd.sum(e)                       # fused full reduce
+    cols = nd.sum(e, axis=0)              # fused reduce-to-shape
+    mx = nd.max(e)
+    assert nd.FUSION_STATS["vm_reduce"] - before["vm_reduce"] == 3
+    assert e._buf is None, "reductions must not materialise the operand"
+    _close(tot.get(), exp.sum(dtype=np.float64), 1e-5)
+    _close(cols.get(), exp.sum(axis=0, dtype=np.float64), 1e-5)
+    assert mx.get() == exp.max()
+    got = e.get()                         # one vm_eval
+    assert nd.FUSION_STATS["vm_eval"] - before["vm_eval"] == 1
+    assert got.dtype == np.float32
+    _close(got, exp, 2e-6)
+    # bool-valued program
+    m = nd.logical_and(nd.greater(dx, 0), nd.less(dy, 0.5))
+    assert m.dtype == np.bool_ and m._expr is not None
+    assert np.array_equal(m.get(), (x > 0) & (y < 0.5))
+    # strided leaves take the generic interpreter kernel
+    t = nd.add(nd.sin(dx.T), dy.T)
+    _close(t.get(), np.sin(x.T) + y.T, 2e-6)
+    # float64 program
+    x64 = rng.standard_normal((33, 7))
+    d64 = nd.asarray(x64)
+    _close(nd.sum(nd.exp(nd.multiply(d64, 0.5))).get(), np.exp(x64 * 0.5).sum(), 1e-13)
+    # integer loops are never fused
+    xi = nd.asarray(np.arange(12))
+    r = nd.add(xi, 3)
+    assert r._expr is None and np.array_equal(r.get(), np.arange(12) + 3)
+
+
+def test_chain_cpu(lazy_nd, on_gpu): _chain(lazy_nd, on_gpu, False)
+@gpu
+def test_chain_gpu(lazy_nd, on_gpu): _chain(lazy_nd, on_gpu, True)
+
+
+def _hazards(nd, on_gpu, want_gpu):
+    if want_gpu != on_gpu:
+        pytest.skip("other twin")
+    x = np.arange(8, dtype=np.float32)
+    dx = nd.asarray(x.copy())
+    pending = nd.multiply(dx, 2.0)
+    assert pending._expr is not None
+    dx += 100.0                           # in-place write to a leaf: the pending value is flushed first
+    assert np.array_equal(pending.get(), x * 2)
+    assert np.array_equal(dx.get(), x + 100)
+    p2 = nd.add(dx, 1.0)
+    dx[2:4] = -1.0                        # setitem on the leaf
+    assert np.array_equal(p2.get(), x + 101)
+    p3 = nd.sin(dx)
+    v = dx[1:5]                           # views of a leaf alias it; writes through the view flush too
+    v *= 0.0
+    assert np.allclose(p3.get(), np.sin(np.where((np.arange(8) >= 2) & (np.arange(8) < 4), -1.0, x + 100)), rtol=1e-6)
+    # a program that would exceed the interpreter (depth / length) is split transparently
+    acc = nd.asarray(np.ones(16, dtype=np.float32))
+    y = acc
+    for i in range(120):
+        y = nd.add(nd.multiply(y, 1.0), 1.0)
+    assert np.array_equal(y.get(), np.full(16, 121.0, dtype=np.float32))
+    z = nd.asarray(np.full(4, 1.5, dtype=np.float32))
+    w = z
+    for i in range(6):                    # tree doubles each step
+        w = nd.multiply(w, w)
+    assert np.allclose(w.get(), np.float32(1.5) ** 64, rtol=1e-5)
+    # views / matmul / gather of a pending array materialise it
+    q = nd.exp(nd.asarray(np.eye(4, dtype=np.float32)))
+    assert np.allclose(q.T.get(), np.exp(np.eye(4)).T)
+    assert np.allclose(nd.matmul(nd.cos(nd.asarray(np.eye(4, dtype=np.float32))), q).get(), np.cos(np.eye(4)) @ np.exp(np.eye(4)), rtol=1e-5)
+
+
+def test_hazards_cpu(lazy_nd, on_gpu): _hazards(lazy_nd, on_gpu, False)
+@gpu
+def test_hazards_gpu(lazy_nd, on_gpu): _hazards(lazy_nd, on_gpu, True)
+
+
+def _sweeps(nd, on_gpu, want_gpu):
+    """cfg3 / cfg4 through the tape: lazy == eager gradients, with far fewer launches."""
+    if want_gpu != on_gpu:
+        pytest.skip("other twin")
+    from minidiff_amd import workloads
+    from minidiff_amd.hip_backend import HipBackendTable
+    from minidiff_amd.tape import build_engine
+    md = build_engine(HipBackendTable, "lazy")
+    nd.set_lazy(False)
+    s_e, step_e = workloads.make_cfg3(md, n=4096)
+    step_e()
+    gx_e, gy_e = s_e["x"].grad.as_numpy(), s_e["y"].grad.as_numpy()
+    c_e, stepc_e = workloads.make_cfg4(md, batch=64, d_in=32, d_out=48)
+    stepc_e()
+    gw_e, gb_e = c_e["W"].grad.as_numpy(), c_e["b"].grad.as_numpy()
+    nd.set_lazy(True)
+    before = dict(nd.FUSION_STATS)
+    s_l, step_l = workloads.make_cfg3(md, n=4096)
+    out = step_l()
+    assert nd.FUSION_STATS["vm_reduce"] - before["vm_reduce"] == 1      # sum((sin(x)*y)**2) in one pass
+    assert nd.FUSION_STATS["vm_eval"] - before["vm_eval"] == 2          # x.grad and y.grad, one pass each
+    _close(s_l["x"].grad.as_numpy(), gx_e, 1e-6)
+    _close(s_l["y"].grad.as_numpy(), gy_e, 1e-6)
+    before = dict(nd.FUSION_STATS)
+    c_l, stepc_l = workloads.make_cfg4(md, batch=64, d_in=32, d_out=48)
+    stepc_l()
+    assert nd.FUSION_STATS["vm_reduce"] - before["vm_reduce"] == 2      # loss sum + fused bias-gradient column sum
+    _close(c_l["W"].grad.as_numpy(), gw_e, 1e-6)
+    _close(c_l["b"].grad.as_numpy(), gb_e, 1e-6)
+
+
+def test_sweeps_cpu(lazy_nd, on_gpu): _sweeps(lazy_nd, on_gpu, False)
+@gpu
+def test_sweeps_gpu(lazy_nd, on_gpu): _sweeps(lazy_nd, on_gpu, True)
