@@ -219,26 +219,34 @@ int mdhip_scatter(const mdhip_index_plan *plan, void *dst, int dtype,
  * reduction (the "fused elementwise + reduce-to-shape backward" of the north
  * star). The caller (minidiff_amd/lazy.py) records chains of
  * backend calls instead of launching them and hands over a POSTFIX program that
- * a fixed interpreter kernel evaluates per element on a 4-deep register stack:
- * no runtime compilation. Values are held in `compute_dtype` (F32 or F64);
+ * a fixed interpreter kernel evaluates per element on a 4-deep register stack
+ * (instructions are prefetched from LDS; most carry their leaf / constant operand
+ * themselves): no runtime compilation. Values are held in `compute_dtype` (F32 or F64);
  * bool values travel as 0/1. Every operator applies the same functor as the
  * eager kernel (csrc/md_ops.h), so per-element results are identical. */
 #define MDHIP_VM_MAX_INSTR 48
 #define MDHIP_VM_MAX_LEAVES 8
-#define MDHIP_VM_MAX_CONSTS 16
 #define MDHIP_VM_STACK 4
+/* instruction kinds */
 enum {
-  MDHIP_VM_PUSH_LEAF = 0, /* arg = leaf index */
-  MDHIP_VM_PUSH_CONST,    /* arg = const index */
-  MDHIP_VM_UNARY,         /* arg = MDHIP_U_* : s0 = f(s0) */
-  MDHIP_VM_BINARY,        /* arg = MDHIP_B_* : s0 = f(s1, s0), pop */
-  MDHIP_VM_WHERE          /* s0 = s2 ? s1 : s0, pop 2 */
+  MDHIP_VM_PUSH = 0, /* push rhs operand (leaf or const) */
+  MDHIP_VM_UNARY,    /* s0 = f(s0), op = MDHIP_U_* */
+  MDHIP_VM_BINARY,   /* op = MDHIP_B_*; operands: see below */
+  MDHIP_VM_WHERE     /* s0 = s2 ? s1 : s0, pops 2 */
 };
+/* operand sources of a BINARY (and the rhs of PUSH) */
+enum { MDHIP_VM_SRC_STACK = 0, MDHIP_VM_SRC_LEAF = 1, MDHIP_VM_SRC_CONST = 2 };
+/* ctrl word: kind[0:2] op[3:7] lhs_src[8:9] lhs_leaf[10:12] rhs_src[13:14] rhs_leaf[15:17].
+ * BINARY: value = op(lhs, rhs). Both STACK: lhs = s1, rhs = s0, pops one. One STACK:
+ * it is s0, replaced in place (the common "x = op(x, leaf|const)" costs no stack traffic).
+ * None STACK: the result is pushed. A CONST operand reads imm[pc] (so at most one per
+ * instruction). */
+#define MDHIP_VM_CTRL(kind, op, ls, ll, rs, rl) \
+  ((uint32_t)(kind) | ((uint32_t)(op) << 3) | ((uint32_t)(ls) << 8) | ((uint32_t)(ll) << 10) | ((uint32_t)(rs) << 13) | ((uint32_t)(rl) << 15))
 typedef struct mdhip_vm_program {
-  int32_t n_instr, n_leaves, n_consts, compute_dtype;
-  uint8_t kind[MDHIP_VM_MAX_INSTR];
-  uint8_t arg[MDHIP_VM_MAX_INSTR];
-  double consts[MDHIP_VM_MAX_CONSTS];
+  int32_t n_instr, n_leaves, compute_dtype, _pad;
+  uint32_t ctrl[MDHIP_VM_MAX_INSTR];
+  double imm[MDHIP_VM_MAX_INSTR];
   mdhip_array leaves[MDHIP_VM_MAX_LEAVES]; /* each broadcast to out's shape (stride 0 on broadcast axes) */
 } mdhip_vm_program;
 /* out[...] = program(...)  (out dtype: compute_dtype, or BOOL for a 0/1 result) */
@@ -249,6 +257,16 @@ int mdhip_vm_eval(const mdhip_vm_program *prog, const mdhip_array *out);
  * Anything else returns MDHIP_EVALUE and the caller materialises first. */
 int mdhip_vm_reduce(const mdhip_vm_program *prog, int reduce_op, const mdhip_array *shape_like,
                     const mdhip_array *out, uint32_t axis_mask);
+
+/* Large programs are specialised at run time: the same instruction sequence is
+ * emitted as straight-line HIP source over the md_ops.h functors, compiled with
+ * hiprtc for gfx950 and cached by signature; the interpreter remains the fallback
+ * (small arrays, no libhiprtc, MDHIP_JIT=0). These two entry points are diagnostics:
+ * compile-only check of a program (kind 0 = eval, 1 = full reduce, 2 = column
+ * reduce; needs no device), and counters {kernels compiled, kernels launched}. */
+int mdhip_vm_jit_probe(const mdhip_vm_program *prog, int kind, int reduce_op, int out_is_bool,
+                       char *log, size_t log_capacity);
+int mdhip_vm_jit_stats(int64_t stats[2]);
 
 /* ======================= data-parallel (RCCL over xGMI) =================== */
 /* One communicator per process (one process per GPU). uid is the 128-byte

@@ -62,18 +62,24 @@ class IndexPlan(C.Structure):
     ]
 
 
-VM_MAX_INSTR, VM_MAX_LEAVES, VM_MAX_CONSTS = 48, 8, 16
+VM_MAX_INSTR, VM_MAX_LEAVES = 48, 8
+VM_PUSH, VM_UNARY, VM_BINARY, VM_WHERE = range(4)
+VM_SRC_STACK, VM_SRC_LEAF, VM_SRC_CONST = range(3)
+
+
+def vm_ctrl(kind, op=0, ls=0, ll=0, rs=0, rl=0) -> int:
+    """MDHIP_VM_CTRL of include/mdhip.h."""
+    return kind | (op << 3) | (ls << 8) | (ll << 10) | (rs << 13) | (rl << 15)
 
 
 class VmProgram(C.Structure):
     _fields_ = [
         ("n_instr", C.c_int32),
         ("n_leaves", C.c_int32),
-        ("n_consts", C.c_int32),
         ("compute_dtype", C.c_int32),
-        ("kind", C.c_uint8 * VM_MAX_INSTR),
-        ("arg", C.c_uint8 * VM_MAX_INSTR),
-        ("consts", C.c_double * VM_MAX_CONSTS),
+        ("_pad", C.c_int32),
+        ("ctrl", C.c_uint32 * VM_MAX_INSTR),
+        ("imm", C.c_double * VM_MAX_INSTR),
         ("leaves", ArrayDesc * VM_MAX_LEAVES),
     ]
 
@@ -107,6 +113,8 @@ _PROTOTYPES = {
     "mdhip_scatter": [_P(IndexPlan), C.c_void_p, C.c_int, _P(ArrayDesc), C.c_int],
     "mdhip_vm_eval": [_P(VmProgram), _P(ArrayDesc)],
     "mdhip_vm_reduce": [_P(VmProgram), C.c_int, _P(ArrayDesc), _P(ArrayDesc), C.c_uint32],
+    "mdhip_vm_jit_probe": [_P(VmProgram), C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t],
+    "mdhip_vm_jit_stats": [_P(C.c_int64)],
     "mdhip_comm_get_unique_id": [_P(C.c_uint8)],
     "mdhip_comm_init": [C.c_int, C.c_int, _P(C.c_uint8)],
     "mdhip_comm_allreduce_sum": [C.c_void_p, C.c_size_t, C.c_int],

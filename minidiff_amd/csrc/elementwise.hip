@@ -261,7 +261,7 @@ struct HipExec {
       int status = MDHIP_OK;
       if (try_binary_fast<F, Tc, To, Ts, Ts>(it, g, a, b, out, sa, sb, &status)) return status;
       // bool mask times float payload (relu / where gradients: definitions.py:555-559)
-      if constexpr (std::is_same<F, BMul>::value && md_is_float<Tc>::value) {
+      if constexpr (md_same<F, BMul>::value && md_is_float<Tc>::value) {
         if (try_binary_fast<F, Tc, To, Ts, b8>(it, g, a, b, out, sa, sb, &status)) return status;
         if (try_binary_fast<F, Tc, To, b8, Ts>(it, g, a, b, out, sa, sb, &status)) return status;
       }

@@ -8,15 +8,18 @@
 // program interpreted per element (csrc/md_vm.h) — the leaves are read once, the
 // result is written (or reduced) once: HBM-bound at the *fused* byte count.
 //
-// Kernels (all wave-uniform control flow; 4 elements per lane on the vector path):
+// Kernels (all wave-uniform control flow; 16 elements per lane per interpreter pass on
+// the vector path, which amortises the per-step fetch/decode/branch cost):
 //   k_vm_eval_fast     (rows, inner) geometry: leaves contiguous / row- or column-
-//                      broadcast / stride-0, 16-B loads+stores
+//                      broadcast / stride-0, 16-B loads+stores, 16 elements per lane per pass
 //   k_vm_eval_generic  any <=8-D strides, one element per lane
 //   k_vm_reduce_all    full reduction of the program's value (grid-strided sweep,
 //                      block partials + finishing block) — fused "...sum()"
 //   k_vm_reduce_cols   2-D program reduced over rows: lane owns 4 columns, rows
 //                      split over gridDim.y — fused reduce-to-shape (bias gradient)
 // Reductions are deterministic (no atomics).
+#include <vector>
+
 #include "md_hip.h"
 #include "md_vm.h"
 
@@ -25,34 +28,42 @@ extern "C" int mdhip_free(void *);
 
 namespace {
 
+constexpr int VG = 4;        // 16-B vector groups per lane per interpreter pass
+constexpr int VW = 4 * VG;   // lanes of the operand stack per thread
+
+// leaf load for VG element groups of the (rows, inner) geometry: VG independent 16-B loads
 template <class T> struct FastLoader {
   const MdVmDev &P;
-  int64_t row, c;
-  __device__ __forceinline__ void operator()(int l, T (&d)[4]) const {
+  int64_t row[VG], c[VG];
+  template <class S> __device__ __forceinline__ void vec(const MdVmLeaf &L, T (&d)[VW]) const {
+    MdVec<S, 4> v[VG];
+#pragma unroll
+    for (int g = 0; g < VG; ++g) v[g] = *reinterpret_cast<const MdVec<S, 4> *>((const S *)L.p + row[g] * L.os + c[g]);
+#pragma unroll
+    for (int g = 0; g < VG; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (md_same<S, uint8_t>::value) d[4 * g + j] = (T)(v[g].v[j] != 0);
+        else d[4 * g + j] = (T)v[g].v[j];
+      }
+  }
+  __device__ __forceinline__ void operator()(int l, T (&d)[VW]) const {
     const MdVmLeaf &L = P.leaf[l];
-    const int64_t base = row * L.os;
     if (L.is) {
       switch (L.dtype) {
-        case MDHIP_F32: { MdVec<float, 4> v = *reinterpret_cast<const MdVec<float, 4> *>((const float *)L.p + base + c);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) d[j] = (T)v.v[j]; } break;
-        case MDHIP_F64: { MdVec<double, 4> v = *reinterpret_cast<const MdVec<double, 4> *>((const double *)L.p + base + c);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) d[j] = (T)v.v[j]; } break;
-        case MDHIP_BOOL: { MdVec<uint8_t, 4> v = *reinterpret_cast<const MdVec<uint8_t, 4> *>((const uint8_t *)L.p + base + c);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) d[j] = (T)(v.v[j] != 0); } break;
-        case MDHIP_I32: { MdVec<int32_t, 4> v = *reinterpret_cast<const MdVec<int32_t, 4> *>((const int32_t *)L.p + base + c);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) d[j] = (T)v.v[j]; } break;
-        default: { MdVec<int64_t, 4> v = *reinterpret_cast<const MdVec<int64_t, 4> *>((const int64_t *)L.p + base + c);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) d[j] = (T)v.v[j]; } break;
+        case MDHIP_F32: vec<float>(L, d); break;
+        case MDHIP_F64: vec<double>(L, d); break;
+        case MDHIP_BOOL: vec<uint8_t>(L, d); break;
+        case MDHIP_I32: vec<int32_t>(L, d); break;
+        default: vec<int64_t>(L, d); break;
       }
     } else {
-      const T s = md_load<T>(L.p, L.dtype, base);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d[j] = s;
+      for (int g = 0; g < VG; ++g) {
+        const T s = md_load<T>(L.p, L.dtype, row[g] * L.os);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[4 * g + j] = s;
+      }
     }
   }
 };
@@ -70,6 +81,34 @@ template <class T> struct FastLoader1 {  // single element on the fast geometry 
   }
 };
 
+// Program staging: every block copies the (<= 48 x 16 B) program from the kernarg
+// segment into LDS once (static kernarg offsets: the scalar loads overlap), then
+// each interpreter step reads its instruction with one broadcast ds_read_b128 that
+// was issued one instruction earlier.
+__device__ __forceinline__ void vm_stage_program(const MdVmDev &P, MdVmInstr *prog) {
+#pragma unroll
+  for (int i = 0; i < MDHIP_VM_MAX_INSTR; ++i) {
+    if (i < P.n_instr && threadIdx.x == (unsigned)i) prog[i] = P.code[i];
+  }
+  if (threadIdx.x == 0) { prog[MDHIP_VM_MAX_INSTR].ctrl = 0; prog[MDHIP_VM_MAX_INSTR].imm = 0.0; }
+  __syncthreads();
+}
+struct LdsFetch {
+  const MdVmInstr *prog;
+  uint4 nxt;
+  __device__ __forceinline__ void prefetch(int pc) { nxt = *reinterpret_cast<const uint4 *>(prog + pc); }
+  __device__ __forceinline__ void operator()(int, uint32_t &c, double &imm) const {
+    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt.x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt.z);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt.w);
+    imm = __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+  }
+};
+#define MD_VM_PROLOGUE                                         \
+  __shared__ MdVmInstr s_prog[MDHIP_VM_MAX_INSTR + 1];         \
+  vm_stage_program(P, s_prog);                                 \
+  LdsFetch fetch{s_prog, uint4{0, 0, 0, 0}}
+
 __device__ __forceinline__ void vm_row_col(int64_t v, int64_t nv, int64_t rows, int64_t &row, int64_t &cv) {
   if (rows == 1) { row = 0; cv = v; }
   else if ((uint64_t)v < 0x100000000ull && (uint64_t)nv < 0x100000000ull) {
@@ -80,25 +119,39 @@ __device__ __forceinline__ void vm_row_col(int64_t v, int64_t nv, int64_t rows, 
 
 template <class T, class To>
 __global__ void __launch_bounds__(MD_BLOCK) k_vm_eval_fast(MdVmDev P, To *out, int64_t rows, int64_t inner) {
+  MD_VM_PROLOGUE;
   const int64_t nv = inner >> 2, total = rows * nv;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gs = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t v = gid; v < total; v += gs) {
-    int64_t row, cv;
-    vm_row_col(v, nv, rows, row, cv);
-    FastLoader<T> ld{P, row, cv << 2};
-    T r[4];
-    md_vm_run<T, 4>(P.n_instr, P.kind, P.arg, P.consts, ld, r);
-    MdVec<To, 4> o;
+  for (int64_t v0 = gid; v0 < total; v0 += VG * gs) {
+    FastLoader<T> ld{P, {}, {}};
+    bool ok[VG];
+    int64_t orow[VG], ocol[VG];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o.v[j] = md_cast<To>(r[j]);
-    *reinterpret_cast<MdVec<To, 4> *>(out + row * inner + (cv << 2)) = o;
+    for (int g = 0; g < VG; ++g) {
+      const int64_t v = v0 + g * gs;
+      ok[g] = v < total;
+      int64_t row, cv;
+      vm_row_col(ok[g] ? v : v0, nv, rows, row, cv);   // out-of-range groups recompute group 0, unstored
+      ld.row[g] = orow[g] = row;
+      ld.c[g] = ocol[g] = cv << 2;
+    }
+    T r[VW];
+    md_vm_run<T, VW>(P.n_instr, fetch, ld, r);
+#pragma unroll
+    for (int g = 0; g < VG; ++g) {
+      if (!ok[g]) continue;
+      MdVec<To, 4> o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.v[j] = md_cast<To>(r[4 * g + j]);
+      *reinterpret_cast<MdVec<To, 4> *>(out + orow[g] * inner + ocol[g]) = o;
+    }
   }
   if (rows == 1) {
     const int64_t t0 = nv << 2;
     if (gid < inner - t0) {
       FastLoader1<T> ld{P, 0, t0 + gid};
       T r[1];
-      md_vm_run<T, 1>(P.n_instr, P.kind, P.arg, P.consts, ld, r);
+      md_vm_run<T, 1>(P.n_instr, fetch, ld, r);
       out[t0 + gid] = md_cast<To>(r[0]);
     }
   }
@@ -106,6 +159,7 @@ __global__ void __launch_bounds__(MD_BLOCK) k_vm_eval_fast(MdVmDev P, To *out, i
 
 template <class T, class To>
 __global__ void __launch_bounds__(MD_BLOCK) k_vm_eval_generic(MdVmDev P, MdVmIter it, To *out) {
+  MD_VM_PROLOGUE;
   const int64_t gs = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < it.total; i += gs) {
     int64_t offs[MDHIP_VM_MAX_LEAVES + 1];
@@ -119,7 +173,7 @@ __global__ void __launch_bounds__(MD_BLOCK) k_vm_eval_generic(MdVmDev P, MdVmIte
     }
     ScalarLoader<T> ld{P, offs};
     T r[1];
-    md_vm_run<T, 1>(P.n_instr, P.kind, P.arg, P.consts, ld, r);
+    md_vm_run<T, 1>(P.n_instr, fetch, ld, r);
     out[offs[MDHIP_VM_MAX_LEAVES]] = md_cast<To>(r[0]);
   }
 }
@@ -141,28 +195,43 @@ template <class R, class T> __device__ __forceinline__ T vm_block_reduce(T v, T 
 
 template <class R, class T>
 __global__ void __launch_bounds__(MD_BLOCK) k_vm_reduce_all(MdVmDev P, int64_t rows, int64_t inner, T *partial) {
+  MD_VM_PROLOGUE;
   __shared__ T smem[MD_BLOCK / 64];
   const int64_t nv = inner >> 2, total = rows * nv;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gs = (int64_t)gridDim.x * blockDim.x;
-  T a[4];
+  T a[VW];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) a[j] = R::template identity<T>();
-  for (int64_t v = gid; v < total; v += gs) {
-    int64_t row, cv;
-    vm_row_col(v, nv, rows, row, cv);
-    FastLoader<T> ld{P, row, cv << 2};
-    T r[4];
-    md_vm_run<T, 4>(P.n_instr, P.kind, P.arg, P.consts, ld, r);
+  for (int j = 0; j < VW; ++j) a[j] = R::template identity<T>();
+  for (int64_t v0 = gid; v0 < total; v0 += VG * gs) {
+    FastLoader<T> ld{P, {}, {}};
+    bool ok[VG];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = R::combine(a[j], r[j]);
+    for (int g = 0; g < VG; ++g) {
+      const int64_t v = v0 + g * gs;
+      ok[g] = v < total;
+      int64_t row, cv;
+      vm_row_col(ok[g] ? v : v0, nv, rows, row, cv);
+      ld.row[g] = row;
+      ld.c[g] = cv << 2;
+    }
+    T r[VW];
+    md_vm_run<T, VW>(P.n_instr, fetch, ld, r);
+#pragma unroll
+    for (int g = 0; g < VG; ++g)
+      if (ok[g]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[4 * g + j] = R::combine(a[4 * g + j], r[4 * g + j]);
+      }
   }
-  T acc = R::combine(R::combine(a[0], a[1]), R::combine(a[2], a[3]));
+  T acc = R::template identity<T>();
+#pragma unroll
+  for (int j = 0; j < VW; ++j) acc = R::combine(acc, a[j]);
   if (rows == 1) {
     const int64_t t0 = nv << 2;
     if (gid < inner - t0) {
       FastLoader1<T> ld{P, 0, t0 + gid};
       T r[1];
-      md_vm_run<T, 1>(P.n_instr, P.kind, P.arg, P.consts, ld, r);
+      md_vm_run<T, 1>(P.n_instr, fetch, ld, r);
       acc = R::combine(acc, r[0]);
     }
   }
@@ -178,41 +247,45 @@ __global__ void __launch_bounds__(MD_BLOCK) k_vm_finish_all(const T *partial, in
   if (threadIdx.x == 0) out[0] = acc;
 }
 
-// 2-D program [n_red rows][n_out cols] reduced over rows; lane owns 4 columns.
+// 2-D program [n_red rows][n_out cols] reduced over rows; a lane owns 4 columns and
+// takes rows r, r+4, r+8, r+12 per interpreter pass (four 16-B loads per leaf in flight).
 template <class R, class T, bool FINAL>
 __global__ void __launch_bounds__(MD_BLOCK) k_vm_reduce_cols(MdVmDev P, int64_t n_out, int64_t n_red, int64_t chunk, T *dst) {
+  MD_VM_PROLOGUE;
   __shared__ T smem[3][64][4];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int64_t col = ((int64_t)blockIdx.x * 64 + cx) * 4;
   const int64_t s = blockIdx.y, r0 = s * chunk;
   int64_t r1 = r0 + chunk;
   if (r1 > n_red) r1 = n_red;
-  T a[2][4];
+  T a[VW];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int j = 0; j < VW; ++j) a[j] = R::template identity<T>();
+  // every lane of a wave runs the interpreter together (uniform control flow); lanes past
+  // the last column recompute column group 0 of their block and are never stored
+  const int64_t lcol = col < n_out ? col : (int64_t)blockIdx.x * 256;
+  for (int64_t r = r0 + ry; r < r1; r += 4 * VG) {
+    FastLoader<T> ld{P, {}, {}};
+    bool ok[VG];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[u][j] = R::template identity<T>();
-  if (col < n_out) {
-    int64_t r = r0 + ry;
-    for (; r + 4 < r1; r += 8) {
-      T v0[4], v1[4];
-      FastLoader<T> l0{P, r, col}, l1{P, r + 4, col};
-      md_vm_run<T, 4>(P.n_instr, P.kind, P.arg, P.consts, l0, v0);
-      md_vm_run<T, 4>(P.n_instr, P.kind, P.arg, P.consts, l1, v1);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { a[0][j] = R::combine(a[0][j], v0[j]); a[1][j] = R::combine(a[1][j], v1[j]); }
+    for (int g = 0; g < VG; ++g) {
+      const int64_t rr = r + 4 * g;
+      ok[g] = rr < r1;
+      ld.row[g] = ok[g] ? rr : r;
+      ld.c[g] = lcol;
     }
-    for (; r < r1; r += 4) {
-      T v0[4];
-      FastLoader<T> l0{P, r, col};
-      md_vm_run<T, 4>(P.n_instr, P.kind, P.arg, P.consts, l0, v0);
+    T v[VW];
+    md_vm_run<T, VW>(P.n_instr, fetch, ld, v);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a[0][j] = R::combine(a[0][j], v0[j]);
-    }
+    for (int g = 0; g < VG; ++g)
+      if (ok[g]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[4 * g + j] = R::combine(a[4 * g + j], v[4 * g + j]);
+      }
   }
   T tot[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) tot[j] = R::combine(a[0][j], a[1][j]);
+  for (int j = 0; j < 4; ++j) tot[j] = R::combine(R::combine(a[j], a[4 + j]), R::combine(a[8 + j], a[12 + j]));
   if (ry > 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) smem[ry - 1][cx][j] = tot[j];
@@ -227,14 +300,16 @@ __global__ void __launch_bounds__(MD_BLOCK) k_vm_reduce_cols(MdVmDev P, int64_t 
   }
 }
 
+}  // namespace
+#include "fusion_jit.inc"
+namespace {
+
 // ------------------------------------------------------------------------ host ----
 static void to_dev(const mdhip_vm_program *pr, MdVmDev *D) {
   memset(D, 0, sizeof *D);
   D->n_instr = pr->n_instr;
   D->n_leaves = pr->n_leaves;
-  memcpy(D->kind, pr->kind, sizeof D->kind);
-  memcpy(D->arg, pr->arg, sizeof D->arg);
-  memcpy(D->consts, pr->consts, sizeof D->consts);
+  for (int i = 0; i < pr->n_instr; ++i) { D->code[i].ctrl = pr->ctrl[i]; D->code[i].imm = pr->imm[i]; }
   for (int l = 0; l < pr->n_leaves; ++l) {
     D->leaf[l].p = pr->leaves[l].data;
     D->leaf[l].dtype = pr->leaves[l].dtype;
@@ -279,7 +354,15 @@ template <class T> static int eval_typed(const mdhip_vm_program *pr, const mdhip
   int64_t rows, inner;
   const bool to_bool = out->dtype == MDHIP_BOOL;
   if (fast_geometry(it, pr->n_leaves, pr, true, &D, &rows, &inner) && al_for(out->data, out->dtype)) {
-    const int64_t work = rows * (inner >> 2) + (rows == 1 ? 4 : 0);
+    if (jit::enabled() && it.total >= jit::min_elems()) {
+      if (hipFunction_t fn = jit::get(pr, jit::EVAL, 0, to_bool)) {
+        jit::JArgs A;
+        jit::fill_args(&A, pr, D);
+        A.out = out->data; A.rows = rows; A.inner = inner;
+        return jit::launch(fn, A, dim3((unsigned)md_grid_for(rows * (inner >> 2) + (rows == 1 ? 4 : 0))));
+      }
+    }
+    const int64_t work = (rows * (inner >> 2) + VG - 1) / VG + (rows == 1 ? 4 : 0);
     if (to_bool) k_vm_eval_fast<T, b8><<<md_grid_for(work), MD_BLOCK, 0, st>>>(D, (b8 *)out->data, rows, inner);
     else k_vm_eval_fast<T, T><<<md_grid_for(work), MD_BLOCK, 0, st>>>(D, (T *)out->data, rows, inner);
     return MD_LAUNCH_CHECK("vm_eval(fast)");
@@ -292,7 +375,7 @@ template <class T> static int eval_typed(const mdhip_vm_program *pr, const mdhip
 static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 template <class R, class T>
-static int reduce_typed(const mdhip_vm_program *pr, const mdhip_array *shape_like, const mdhip_array *out, uint32_t mask) {
+static int reduce_typed(const mdhip_vm_program *pr, int rop, const mdhip_array *shape_like, const mdhip_array *out, uint32_t mask) {
   const int nd = shape_like->ndim;
   const uint32_t all = nd ? ((1u << nd) - 1u) : 0u;
   MdVmIter it;
@@ -305,11 +388,20 @@ static int reduce_typed(const mdhip_vm_program *pr, const mdhip_array *shape_lik
   if (!fast_geometry(it, pr->n_leaves, pr, false, &D, &rows, &inner)) return md_fail(MDHIP_EVALUE, "vm_reduce: geometry not supported");
   if (((uintptr_t)out->data & 15) != 0) return md_fail(MDHIP_EVALUE, "vm_reduce: unaligned output");
   if (mask == all) {
-    const int64_t work = rows * (inner >> 2) + (rows == 1 ? 4 : 0);
+    hipFunction_t fn = (jit::enabled() && it.total >= jit::min_elems()) ? jit::get(pr, jit::RED_ALL, rop, false) : nullptr;
+    const int64_t work = fn ? rows * (inner >> 2) + (rows == 1 ? 4 : 0) : (rows * (inner >> 2) + VG - 1) / VG + (rows == 1 ? 4 : 0);
     const int grid = md_grid_for(work);
     void *partial = nullptr;
     MD_TRY(mdhip_alloc((size_t)grid * sizeof(T), &partial));
-    k_vm_reduce_all<R, T><<<grid, MD_BLOCK, 0, st>>>(D, rows, inner, (T *)partial);
+    if (fn) {
+      jit::JArgs A;
+      jit::fill_args(&A, pr, D);
+      A.out = partial; A.rows = rows; A.inner = inner;
+      int rc = jit::launch(fn, A, dim3((unsigned)grid));
+      if (rc != MDHIP_OK) { mdhip_free(partial); return rc; }
+    } else {
+      k_vm_reduce_all<R, T><<<grid, MD_BLOCK, 0, st>>>(D, rows, inner, (T *)partial);
+    }
     k_vm_finish_all<R, T><<<1, MD_BLOCK, 0, st>>>((const T *)partial, grid, (T *)out->data);
     int rc = MD_LAUNCH_CHECK("vm_reduce(all)");
     mdhip_free(partial);
@@ -323,22 +415,35 @@ static int reduce_typed(const mdhip_vm_program *pr, const mdhip_array *shape_lik
     if (splits > n_red / 32) splits = n_red / 32;
     if (splits > 65535) splits = 65535;
     if (splits < 1) splits = 1;
-    const int64_t chunk = ceil_div(ceil_div(n_red, splits), 8) * 8;
+    const int64_t chunk = ceil_div(ceil_div(n_red, splits), 16) * 16;
     splits = ceil_div(n_red, chunk);
+    hipFunction_t fn = (jit::enabled() && it.total >= jit::min_elems()) ? jit::get(pr, jit::RED_COLS, rop, false) : nullptr;
+    jit::JArgs A;
+    if (fn) {
+      jit::fill_args(&A, pr, D);
+      A.rows = rows; A.inner = inner; A.n_out = n_out; A.n_red = n_red; A.chunk = chunk;
+    }
     if (splits == 1) {
+      if (fn) { A.out = out->data; return jit::launch(fn, A, dim3((unsigned)bx, 1)); }
       k_vm_reduce_cols<R, T, true><<<dim3((unsigned)bx, 1), MD_BLOCK, 0, st>>>(D, n_out, n_red, chunk, (T *)out->data);
       return MD_LAUNCH_CHECK("vm_reduce(cols)");
     }
     void *partial = nullptr;
     MD_TRY(mdhip_alloc((size_t)(splits * n_out) * sizeof(T), &partial));
-    k_vm_reduce_cols<R, T, false><<<dim3((unsigned)bx, (unsigned)splits), MD_BLOCK, 0, st>>>(D, n_out, n_red, chunk, (T *)partial);
+    if (fn) {
+      A.out = partial;
+      int rc = jit::launch(fn, A, dim3((unsigned)bx, (unsigned)splits));
+      if (rc != MDHIP_OK) { mdhip_free(partial); return rc; }
+    } else {
+      k_vm_reduce_cols<R, T, false><<<dim3((unsigned)bx, (unsigned)splits), MD_BLOCK, 0, st>>>(D, n_out, n_red, chunk, (T *)partial);
+    }
     // second pass: a one-instruction program over the partial buffer
     MdVmDev F;
     memset(&F, 0, sizeof F);
     F.n_instr = 1; F.n_leaves = 1;
-    F.kind[0] = MDHIP_VM_PUSH_LEAF; F.arg[0] = 0;
+    F.code[0].ctrl = MDHIP_VM_CTRL(MDHIP_VM_PUSH, 0, 0, 0, MDHIP_VM_SRC_LEAF, 0);
     F.leaf[0].p = partial; F.leaf[0].os = n_out; F.leaf[0].is = 1; F.leaf[0].dtype = md_dtype_of<T>::value;
-    const int64_t chunk2 = ceil_div(splits, 8) * 8;
+    const int64_t chunk2 = ceil_div(splits, 16) * 16;
     k_vm_reduce_cols<R, T, true><<<dim3((unsigned)bx, 1), MD_BLOCK, 0, st>>>(F, n_out, splits, chunk2, (T *)out->data);
     int rc = MD_LAUNCH_CHECK("vm_reduce(cols,split)");
     mdhip_free(partial);
@@ -359,14 +464,31 @@ int mdhip_vm_eval(const mdhip_vm_program *pr, const mdhip_array *out) {
   return pr->compute_dtype == MDHIP_F32 ? eval_typed<float>(pr, out) : eval_typed<double>(pr, out);
 }
 
+int mdhip_vm_jit_probe(const mdhip_vm_program *pr, int kind, int reduce_op, int out_is_bool, char *log, size_t log_cap) {
+  MD_TRY(md_vm_check(pr));
+  if (kind < 0 || kind > 2) return md_fail(MDHIP_EVALUE, "jit probe: kind must be 0 (eval), 1 (reduce all) or 2 (reduce columns)");
+  std::vector<char> code;
+  std::string l;
+  const int rc = jit::compile(jit::gen_source(pr, kind, reduce_op, out_is_bool != 0), &code, &l);
+  if (log && log_cap) { strncpy(log, l.c_str(), log_cap - 1); log[log_cap - 1] = 0; }
+  if (rc != 0) return md_fail(MDHIP_ERUNTIME, "fused-kernel compilation failed: %.300s", l.c_str());
+  return MDHIP_OK;
+}
+
+int mdhip_vm_jit_stats(int64_t stats[2]) {
+  stats[0] = jit::g_compiled;
+  stats[1] = jit::g_launched;
+  return MDHIP_OK;
+}
+
 int mdhip_vm_reduce(const mdhip_vm_program *pr, int op, const mdhip_array *shape_like, const mdhip_array *out, uint32_t mask) {
   MD_TRY(md_vm_check(pr));
   MD_TRY(md_check_array(shape_like, "vm shape"));
   MD_TRY(md_check_array(out, "vm out"));
   if (out->dtype != pr->compute_dtype) return md_fail(MDHIP_ETYPE, "vm_reduce: out dtype must be the compute dtype");
 #define MD_VMR(R)                                                                                         \
-  return pr->compute_dtype == MDHIP_F32 ? reduce_typed<R, float>(pr, shape_like, out, mask)               \
-                                        : reduce_typed<R, double>(pr, shape_like, out, mask)
+  return pr->compute_dtype == MDHIP_F32 ? reduce_typed<R, float>(pr, op, shape_like, out, mask)           \
+                                        : reduce_typed<R, double>(pr, op, shape_like, out, mask)
   switch (op) {
     case MDHIP_R_SUM: MD_VMR(RSum);
     case MDHIP_R_PROD: MD_VMR(RProd);

@@ -250,7 +250,7 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
 struct HipExec {
   template <class T> static int gemm(const MdGemm &g) {
     if (g.batch > 65535) return md_fail(MDHIP_EVALUE, "matmul: batch extent %lld exceeds 65535", (long long)g.batch);
-    if constexpr (std::is_same<T, float>::value) {
+    if constexpr (md_same<T, float>::value) {
       // each operand must have a unit stride along k or along its other axis
       const bool a_kc = g.a_ks == 1 || g.K == 1, a_mc = g.a_ms == 1 || g.M == 1;
       const bool b_kc = g.b_ks == 1 || g.K == 1, b_nc = g.b_ns == 1 || g.N == 1;

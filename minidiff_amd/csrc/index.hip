@@ -78,7 +78,7 @@ __global__ void k_scatter_serial(mdhip_index_plan pl, int64_t total, T *dst, Val
     const int64_t off = md_plan_offset(pl, i, pos, &oob);
     const T val = val_at<T>(v, s, pl, pos);
     if constexpr (MODE == MDHIP_SCATTER_ADD) {
-      if constexpr (std::is_same<T, uint8_t>::value) dst[off] = (uint8_t)(dst[off] || val);
+      if constexpr (md_same<T, uint8_t>::value) dst[off] = (uint8_t)(dst[off] || val);
       else dst[off] = BAdd::apply(dst[off], val);
     } else {
       dst[off] = val;
@@ -175,7 +175,7 @@ static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, c
     return MD_LAUNCH_CHECK("scatter(serial)");
   }
   if (mode == MDHIP_SCATTER_SET) return scatter_ordered<T, MDHIP_SCATTER_SET>(pl, total, dst, v, s);
-  if constexpr (std::is_same<T, uint8_t>::value) {
+  if constexpr (md_same<T, uint8_t>::value) {
     k_scatter_serial<T, MDHIP_SCATTER_ADD><<<1, 64, 0, st>>>(*pl, total, (T *)dst, v, s);
     return MD_LAUNCH_CHECK("scatter(add,bool)");
   } else if constexpr (!is_fp) {

@@ -61,7 +61,7 @@ template <> struct md_dtype_of<double> { static constexpr int value = MDHIP_F64;
 // ---- typed element access with a runtime source dtype ------------------------
 // Tc == uint8_t means "truth value": any source dtype loads as (x != 0).
 template <class Tc> MD_HD Tc md_load(const void *p, int dtype, int64_t off) {
-  if constexpr (std::is_same<Tc, uint8_t>::value) {
+  if constexpr (md_same<Tc, uint8_t>::value) {
     switch (dtype) {
       case MDHIP_BOOL: return (uint8_t)(((const uint8_t *)p)[off] != 0);
       case MDHIP_I32: return (uint8_t)(((const int32_t *)p)[off] != 0);
@@ -84,7 +84,7 @@ template <class To, class R> MD_HD To md_to_out(R r) { return md_cast<To>(r); }
 
 // scalar operand -> compute type
 template <class Tc> static inline Tc md_scalar_as(const mdhip_array *s) {
-  if constexpr (std::is_same<Tc, uint8_t>::value) {
+  if constexpr (md_same<Tc, uint8_t>::value) {
     return md_dtype_is_float(s->dtype) ? (uint8_t)(s->scalar_f != 0.0) : (uint8_t)(s->scalar_i != 0);
   } else {
     return md_dtype_is_float(s->dtype) ? md_cast<Tc>(s->scalar_f) : md_cast<Tc>(s->scalar_i);

@@ -234,7 +234,7 @@ template <class X> int md_reduce_dispatch(int op, const mdhip_array *x, const md
       if (pl.n_red == 0) return md_fail(MDHIP_EVALUE, "zero-size array to reduction operation %s which has no identity", op == MDHIP_R_MAX ? "maximum" : "minimum");
       if (odt != xdt) return md_fail(MDHIP_ETYPE, "max/min: out dtype must equal input dtype");
       MD_ALL_SWITCH(xdt, T, {
-        using To = typename std::conditional<std::is_same<T, uint8_t>::value, b8, T>::type;
+        using To = typename md_cond<md_same<T, uint8_t>::value, b8, T>::type;
         return op == MDHIP_R_MAX ? X::template reduce<RMax, T, To>(pl, x, out)
                                  : X::template reduce<RMin, T, To>(pl, x, out);
       })

@@ -9,16 +9,41 @@
 // divisor), integer power by repeated squaring with wrap-around, NaN-propagating
 // maximum/minimum, sign(NaN)=NaN, integer division by zero -> 0.
 #pragma once
+// Also compiled at RUN TIME by hiprtc (fusion_jit.hip embeds this file's text in front
+// of the generated fused kernels), where no libc / libstdc++ headers exist: keep it
+// free of std:: and of host-only constructs.
+#if defined(__HIPCC_RTC__)
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+#ifndef INFINITY
+#define INFINITY __builtin_inff()
+#endif
+#ifndef INT64_MIN
+#define INT64_MIN (-9223372036854775807LL - 1)
+#define INT64_MAX 9223372036854775807LL
+#define INT32_MIN (-2147483647 - 1)
+#define INT32_MAX 2147483647
+#endif
+#define MD_HD __device__ __forceinline__
+#else
 #include <math.h>
 #include <stdint.h>
-
-#include <type_traits>
-
 #if defined(__HIPCC__)
 #define MD_HD __host__ __device__ __forceinline__
 #else
 #define MD_HD inline
 #endif
+#endif
+
+// minimal type utilities (no <type_traits>: see above)
+template <bool C, class A, class B> struct md_cond { using type = A; };
+template <class A, class B> struct md_cond<false, A, B> { using type = B; };
+template <class A, class B> struct md_same { static constexpr bool value = false; };
+template <class A> struct md_same<A, A> { static constexpr bool value = true; };
 
 // numpy.bool_ : one byte holding 0 or 1. A distinct type so that conversions to
 // and from it normalise (x != 0) instead of truncating.
@@ -103,7 +128,7 @@ struct UAbs {
     } else if constexpr (sizeof(T) == 1) {
       return x;
     } else {
-      using U = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;
+      using U = typename md_cond<sizeof(T) == 8, uint64_t, uint32_t>::type;
       return x < 0 ? (T)((U)0 - (U)x) : x;
     }
   }
@@ -113,7 +138,7 @@ struct UNeg {
     if constexpr (md_is_float<T>::value) {
       return -x;
     } else {
-      using U = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;
+      using U = typename md_cond<sizeof(T) == 8, uint64_t, uint32_t>::type;
       return (T)((U)0 - (U)x);
     }
   }
@@ -184,8 +209,8 @@ struct UIsnan {
 
 // ============================ binary ==========================================
 template <class T> struct md_uint_of {
-  using type = typename std::conditional<sizeof(T) == 8, uint64_t,
-               typename std::conditional<sizeof(T) == 4, uint32_t, uint8_t>::type>::type;
+  using type = typename md_cond<sizeof(T) == 8, uint64_t,
+               typename md_cond<sizeof(T) == 4, uint32_t, uint8_t>::type>::type;
 };
 struct BAdd {
   template <class T> static MD_HD T apply(T a, T b) {

@@ -1,8 +1,19 @@
-// md_vm.h — the postfix expression interpreter behind mdhip_vm_eval / mdhip_vm_reduce.
-// Shared by the gfx950 kernels (fusion.hip) and the CPU test double. The stack is
-// four named register arrays of W lanes (W = 4 on the vector path), shifted on
-// push/pop with static indices only, so nothing is spilled to scratch; control
-// flow depends only on the program, i.e. it is uniform across a wavefront.
+// md_vm.h — the expression interpreter behind mdhip_vm_eval / mdhip_vm_reduce.
+// Shared by the gfx950 kernels (fusion.hip) and the CPU test double.
+//
+// A program is a short postfix sequence over a 4-deep operand stack kept in named
+// register arrays of W lanes (W = 4 on the vector path; static indices only, so
+// nothing spills to scratch). To keep the per-instruction overhead below the HBM
+// time of the data it touches:
+//   * one interpreter step covers W lanes per thread (16 on the device: four 16-B
+//     vector groups, so a leaf operand is four independent loads in flight) — the
+//     fetch / decode / branch cost of a step is per wave-instruction, not per lane;
+//   * most instructions are operand-fused (s0 = op(s0, leaf|const)), so a chain
+//     costs one instruction per operator and no stack traffic;
+//   * an instruction is 16 bytes {ctrl, pad, imm(double)}; Fetch supplies it — the
+//     device fetches from LDS one instruction ahead (ds_read_b128 broadcast +
+//     readfirstlane), the host double indexes the program directly.
+// Control flow depends only on the program: uniform across a wavefront.
 #pragma once
 #include "md_common.h"
 
@@ -12,12 +23,14 @@ struct MdVmLeaf {
   int32_t is;     // fast geometry: inner stride 0 / 1
   int32_t dtype;
 };
+struct MdVmInstr {
+  uint32_t ctrl, pad;
+  double imm;
+};
 struct MdVmDev {
   int32_t n_instr, n_leaves;
-  uint8_t kind[MDHIP_VM_MAX_INSTR];
-  uint8_t arg[MDHIP_VM_MAX_INSTR];
-  double consts[MDHIP_VM_MAX_CONSTS];
   MdVmLeaf leaf[MDHIP_VM_MAX_LEAVES];
+  MdVmInstr code[MDHIP_VM_MAX_INSTR];
 };
 // generic geometry: (ndim, shape) shared, per-leaf strides
 struct MdVmIter {
@@ -27,77 +40,133 @@ struct MdVmIter {
   int64_t strides[MDHIP_VM_MAX_LEAVES + 1][MDHIP_MAX_NDIM];  // last = out
 };
 
-template <class T> MD_HD T md_vm_unary(int op, T x) {
+#define MD_VM_KIND(c) ((c) & 7u)
+#define MD_VM_OP(c) (((c) >> 3) & 31u)
+#define MD_VM_LS(c) (((c) >> 8) & 3u)
+#define MD_VM_LL(c) (((c) >> 10) & 7u)
+#define MD_VM_RS(c) (((c) >> 13) & 3u)
+#define MD_VM_RL(c) (((c) >> 15) & 7u)
+
+// The opcode switch sits OUTSIDE the W-lane loop: one uniform branch per instruction.
+#define MD_VM_U(code, expr) \
+  case code:                \
+    _Pragma("unroll") for (int j = 0; j < W; ++j) { const T x = s0[j]; s0[j] = (expr); } \
+    break;
+template <class T, int W> MD_HD void md_vm_unary(int op, T (&s0)[W]) {
   switch (op) {
-    case MDHIP_U_COPY: return x;
-    case MDHIP_U_ABS: return UAbs::apply(x);
-    case MDHIP_U_NEG: return UNeg::apply(x);
-    case MDHIP_U_SIGN: return USign::apply(x);
-    case MDHIP_U_CEIL: return UCeil::apply(x);
-    case MDHIP_U_FLOOR: return UFloor::apply(x);
-    case MDHIP_U_SIN: return USin::apply(x);
-    case MDHIP_U_COS: return UCos::apply(x);
-    case MDHIP_U_TAN: return UTan::apply(x);
-    case MDHIP_U_SINH: return USinh::apply(x);
-    case MDHIP_U_COSH: return UCosh::apply(x);
-    case MDHIP_U_TANH: return UTanh::apply(x);
-    case MDHIP_U_EXP: return UExp::apply(x);
-    case MDHIP_U_LOG: return ULog::apply(x);
-    case MDHIP_U_SQRT: return USqrt::apply(x);
-    case MDHIP_U_LOGICAL_NOT: return (T)(x == (T)0);
-    case MDHIP_U_ISNAN: return (T)(x != x);
+    MD_VM_U(MDHIP_U_ABS, UAbs::apply(x))
+    MD_VM_U(MDHIP_U_NEG, UNeg::apply(x))
+    MD_VM_U(MDHIP_U_SIGN, USign::apply(x))
+    MD_VM_U(MDHIP_U_CEIL, UCeil::apply(x))
+    MD_VM_U(MDHIP_U_FLOOR, UFloor::apply(x))
+    MD_VM_U(MDHIP_U_SIN, USin::apply(x))
+    MD_VM_U(MDHIP_U_COS, UCos::apply(x))
+    MD_VM_U(MDHIP_U_TAN, UTan::apply(x))
+    MD_VM_U(MDHIP_U_SINH, USinh::apply(x))
+    MD_VM_U(MDHIP_U_COSH, UCosh::apply(x))
+    MD_VM_U(MDHIP_U_TANH, UTanh::apply(x))
+    MD_VM_U(MDHIP_U_EXP, UExp::apply(x))
+    MD_VM_U(MDHIP_U_LOG, ULog::apply(x))
+    MD_VM_U(MDHIP_U_SQRT, USqrt::apply(x))
+    MD_VM_U(MDHIP_U_LOGICAL_NOT, (T)(x == (T)0))
+    MD_VM_U(MDHIP_U_ISNAN, (T)(x != x))
+    default: break;  // COPY
   }
-  return x;
 }
-template <class T> MD_HD T md_vm_binary(int op, T a, T b) {
+#undef MD_VM_U
+// r[j] = op(a[j], b[j])
+#define MD_VM_B(code, expr) \
+  case code:                \
+    _Pragma("unroll") for (int j = 0; j < W; ++j) { const T a = A[j], b = B[j]; r[j] = (expr); } \
+    break;
+template <class T, int W> MD_HD void md_vm_binary(int op, const T (&A)[W], const T (&B)[W], T (&r)[W]) {
   switch (op) {
-    case MDHIP_B_ADD: return a + b;
-    case MDHIP_B_SUB: return a - b;
-    case MDHIP_B_MUL: return a * b;
-    case MDHIP_B_TRUE_DIV: return a / b;
-    case MDHIP_B_FLOOR_DIV: return BFloorDiv::apply(a, b);
-    case MDHIP_B_MOD: return BMod::apply(a, b);
-    case MDHIP_B_POW: return BPow::apply(a, b);
-    case MDHIP_B_MAXIMUM: return BMaximum::apply(a, b);
-    case MDHIP_B_MINIMUM: return BMinimum::apply(a, b);
-    case MDHIP_B_EQ: return (T)(a == b);
-    case MDHIP_B_NE: return (T)(a != b);
-    case MDHIP_B_LT: return (T)(a < b);
-    case MDHIP_B_LE: return (T)(a <= b);
-    case MDHIP_B_GT: return (T)(a > b);
-    case MDHIP_B_GE: return (T)(a >= b);
-    case MDHIP_B_LAND: return (T)((a != (T)0) && (b != (T)0));
-    case MDHIP_B_LOR: return (T)((a != (T)0) || (b != (T)0));
-    case MDHIP_B_LXOR: return (T)((a != (T)0) != (b != (T)0));
+    MD_VM_B(MDHIP_B_ADD, a + b)
+    MD_VM_B(MDHIP_B_SUB, a - b)
+    MD_VM_B(MDHIP_B_MUL, a * b)
+    MD_VM_B(MDHIP_B_TRUE_DIV, a / b)
+    MD_VM_B(MDHIP_B_FLOOR_DIV, BFloorDiv::apply(a, b))
+    MD_VM_B(MDHIP_B_MOD, BMod::apply(a, b))
+    MD_VM_B(MDHIP_B_POW, BPow::apply(a, b))
+    MD_VM_B(MDHIP_B_MAXIMUM, BMaximum::apply(a, b))
+    MD_VM_B(MDHIP_B_MINIMUM, BMinimum::apply(a, b))
+    MD_VM_B(MDHIP_B_EQ, (T)(a == b))
+    MD_VM_B(MDHIP_B_NE, (T)(a != b))
+    MD_VM_B(MDHIP_B_LT, (T)(a < b))
+    MD_VM_B(MDHIP_B_LE, (T)(a <= b))
+    MD_VM_B(MDHIP_B_GT, (T)(a > b))
+    MD_VM_B(MDHIP_B_GE, (T)(a >= b))
+    MD_VM_B(MDHIP_B_LAND, (T)((a != (T)0) && (b != (T)0)))
+    MD_VM_B(MDHIP_B_LOR, (T)((a != (T)0) || (b != (T)0)))
+    MD_VM_B(MDHIP_B_LXOR, (T)((a != (T)0) != (b != (T)0)))
+    default:
+#pragma unroll
+      for (int j = 0; j < W; ++j) r[j] = A[j];
   }
-  return a;
+}
+#undef MD_VM_B
+
+// Loader concept: void operator()(int leaf, T (&dst)[W]) — loads W lanes of leaf `leaf`
+// (on the device W = 16: four 16-B vector groups per lane, four loads in flight).
+template <class T, int W, class Loader>
+MD_HD void md_vm_operand(uint32_t src, uint32_t leaf, double imm, Loader &load, T (&d)[W]) {
+  if (src == MDHIP_VM_SRC_CONST) {
+    const T c = (T)imm;
+#pragma unroll
+    for (int j = 0; j < W; ++j) d[j] = c;
+  } else {
+    load((int)leaf, d);
+  }
 }
 
-// Loader concept: void operator()(int leaf, T (&dst)[W]) — fills W lanes of leaf `leaf`.
-template <class T, int W, class Loader>
-MD_HD void md_vm_run(const int32_t n_instr, const uint8_t *kind, const uint8_t *arg, const double *consts, Loader &load,
-                     T (&s0)[W]) {
+// Fetch concept: void operator()(int pc, uint32_t &ctrl, double &imm); prefetch(int pc).
+// The cost of one interpreter step (fetch, decode, a handful of taken scalar branches)
+// is per wave-instruction, so W lanes per step amortise it W-fold.
+template <class T, int W, class Fetch, class Loader>
+MD_HD void md_vm_run(const int32_t n_instr, Fetch &fetch, Loader &load, T (&s0)[W]) {
   T s1[W], s2[W], s3[W];
 #pragma unroll
   for (int j = 0; j < W; ++j) { s0[j] = (T)0; s1[j] = (T)0; s2[j] = (T)0; s3[j] = (T)0; }
+  fetch.prefetch(0);
   for (int pc = 0; pc < n_instr; ++pc) {
-    const int k = kind[pc], a = arg[pc];
-    if (k == MDHIP_VM_PUSH_LEAF || k == MDHIP_VM_PUSH_CONST) {
+    uint32_t c;
+    double imm;
+    fetch(pc, c, imm);
+    fetch.prefetch(pc + 1);
+    const uint32_t k = MD_VM_KIND(c);
+    if (k == MDHIP_VM_BINARY) {
+      const uint32_t ls = MD_VM_LS(c), rs = MD_VM_RS(c), op = MD_VM_OP(c);
+      if (ls == MDHIP_VM_SRC_STACK && rs == MDHIP_VM_SRC_STACK) {
+        T t[W];
+        md_vm_binary<T, W>(op, s1, s0, t);
 #pragma unroll
-      for (int j = 0; j < W; ++j) { s3[j] = s2[j]; s2[j] = s1[j]; s1[j] = s0[j]; }
-      if (k == MDHIP_VM_PUSH_LEAF) {
-        load(a, s0);
+        for (int j = 0; j < W; ++j) { s0[j] = t[j]; s1[j] = s2[j]; s2[j] = s3[j]; }
+      } else if (ls == MDHIP_VM_SRC_STACK) {
+        T o[W], t[W];
+        md_vm_operand<T, W>(rs, MD_VM_RL(c), imm, load, o);
+        md_vm_binary<T, W>(op, s0, o, t);
+#pragma unroll
+        for (int j = 0; j < W; ++j) s0[j] = t[j];
+      } else if (rs == MDHIP_VM_SRC_STACK) {
+        T o[W], t[W];
+        md_vm_operand<T, W>(ls, MD_VM_LL(c), imm, load, o);
+        md_vm_binary<T, W>(op, o, s0, t);
+#pragma unroll
+        for (int j = 0; j < W; ++j) s0[j] = t[j];
       } else {
-        const T c = (T)consts[a];
+        T o1[W], o2[W];
+        md_vm_operand<T, W>(ls, MD_VM_LL(c), imm, load, o1);
+        md_vm_operand<T, W>(rs, MD_VM_RL(c), imm, load, o2);
 #pragma unroll
-        for (int j = 0; j < W; ++j) s0[j] = c;
+        for (int j = 0; j < W; ++j) { s3[j] = s2[j]; s2[j] = s1[j]; s1[j] = s0[j]; }
+        md_vm_binary<T, W>(op, o1, o2, s0);
       }
     } else if (k == MDHIP_VM_UNARY) {
+      md_vm_unary<T, W>(MD_VM_OP(c), s0);
+    } else if (k == MDHIP_VM_PUSH) {
 #pragma unroll
-      for (int j = 0; j < W; ++j) s0[j] = md_vm_unary<T>(a, s0[j]);
-    } else if (k == MDHIP_VM_BINARY) {
-#pragma unroll
-      for (int j = 0; j < W; ++j) { s0[j] = md_vm_binary<T>(a, s1[j], s0[j]); s1[j] = s2[j]; s2[j] = s3[j]; }
+      for (int j = 0; j < W; ++j) { s3[j] = s2[j]; s2[j] = s1[j]; s1[j] = s0[j]; }
+      md_vm_operand<T, W>(MD_VM_RS(c), MD_VM_RL(c), imm, load, s0);
     } else {  // WHERE
 #pragma unroll
       for (int j = 0; j < W; ++j) { s0[j] = (s2[j] != (T)0) ? s1[j] : s0[j]; s1[j] = s3[j]; }
@@ -105,23 +174,47 @@ MD_HD void md_vm_run(const int32_t n_instr, const uint8_t *kind, const uint8_t *
   }
 }
 
+// direct fetch from a program in addressable memory (host double; device fallback)
+struct MdVmFetchDirect {
+  const uint32_t *ctrl;
+  const double *imm;
+  MD_HD void prefetch(int) {}
+  MD_HD void operator()(int pc, uint32_t &c, double &i) const { c = ctrl[pc]; i = imm[pc]; }
+};
+
 // ---- validation + geometry, shared by both builds ---------------------------------
 static inline int md_vm_check(const mdhip_vm_program *pr) {
   if (!pr) return md_fail(MDHIP_EVALUE, "vm: null program");
   if (pr->n_instr < 1 || pr->n_instr > MDHIP_VM_MAX_INSTR) return md_fail(MDHIP_EVALUE, "vm: %d instructions (max %d)", pr->n_instr, MDHIP_VM_MAX_INSTR);
   if (pr->n_leaves < 0 || pr->n_leaves > MDHIP_VM_MAX_LEAVES) return md_fail(MDHIP_EVALUE, "vm: %d leaves (max %d)", pr->n_leaves, MDHIP_VM_MAX_LEAVES);
-  if (pr->n_consts < 0 || pr->n_consts > MDHIP_VM_MAX_CONSTS) return md_fail(MDHIP_EVALUE, "vm: %d consts (max %d)", pr->n_consts, MDHIP_VM_MAX_CONSTS);
   if (pr->compute_dtype != MDHIP_F32 && pr->compute_dtype != MDHIP_F64) return md_fail(MDHIP_ETYPE, "vm: compute dtype must be float32 or float64");
   int depth = 0;
   for (int pc = 0; pc < pr->n_instr; ++pc) {
-    const int k = pr->kind[pc], a = pr->arg[pc];
+    const uint32_t c = pr->ctrl[pc];
+    const uint32_t k = MD_VM_KIND(c), op = MD_VM_OP(c), ls = MD_VM_LS(c), rs = MD_VM_RS(c);
+    if (ls == MDHIP_VM_SRC_LEAF && (int)MD_VM_LL(c) >= pr->n_leaves) return md_fail(MDHIP_EVALUE, "vm: leaf index out of range at %d", pc);
+    if (rs == MDHIP_VM_SRC_LEAF && (int)MD_VM_RL(c) >= pr->n_leaves) return md_fail(MDHIP_EVALUE, "vm: leaf index out of range at %d", pc);
+    if (ls > MDHIP_VM_SRC_CONST || rs > MDHIP_VM_SRC_CONST) return md_fail(MDHIP_EVALUE, "vm: bad operand source at %d", pc);
     switch (k) {
-      case MDHIP_VM_PUSH_LEAF: if (a >= pr->n_leaves) return md_fail(MDHIP_EVALUE, "vm: leaf index %d out of range", a); ++depth; break;
-      case MDHIP_VM_PUSH_CONST: if (a >= pr->n_consts) return md_fail(MDHIP_EVALUE, "vm: const index %d out of range", a); ++depth; break;
-      case MDHIP_VM_UNARY: if (depth < 1 || a >= MDHIP_U_COUNT || a == MDHIP_U_INVERT) return md_fail(MDHIP_EVALUE, "vm: bad unary at %d", pc); break;
-      case MDHIP_VM_BINARY: if (depth < 2 || a >= MDHIP_B_COUNT) return md_fail(MDHIP_EVALUE, "vm: bad binary at %d", pc); --depth; break;
-      case MDHIP_VM_WHERE: if (depth < 3) return md_fail(MDHIP_EVALUE, "vm: where needs 3 operands at %d", pc); depth -= 2; break;
-      default: return md_fail(MDHIP_EVALUE, "vm: unknown instruction kind %d", k);
+      case MDHIP_VM_PUSH:
+        if (rs == MDHIP_VM_SRC_STACK) return md_fail(MDHIP_EVALUE, "vm: PUSH needs a leaf or const at %d", pc);
+        ++depth;
+        break;
+      case MDHIP_VM_UNARY:
+        if (depth < 1 || op >= MDHIP_U_COUNT || op == MDHIP_U_INVERT) return md_fail(MDHIP_EVALUE, "vm: bad unary at %d", pc);
+        break;
+      case MDHIP_VM_BINARY: {
+        if (op >= MDHIP_B_COUNT) return md_fail(MDHIP_EVALUE, "vm: bad binary op at %d", pc);
+        if (ls == MDHIP_VM_SRC_CONST && rs == MDHIP_VM_SRC_CONST) return md_fail(MDHIP_EVALUE, "vm: two const operands at %d", pc);
+        const int need = (ls == MDHIP_VM_SRC_STACK) + (rs == MDHIP_VM_SRC_STACK);
+        if (depth < need) return md_fail(MDHIP_EVALUE, "vm: stack underflow at %d", pc);
+        depth += 1 - need;
+      } break;
+      case MDHIP_VM_WHERE:
+        if (depth < 3) return md_fail(MDHIP_EVALUE, "vm: where needs 3 operands at %d", pc);
+        depth -= 2;
+        break;
+      default: return md_fail(MDHIP_EVALUE, "vm: unknown instruction kind %u", k);
     }
     if (depth > MDHIP_VM_STACK) return md_fail(MDHIP_EVALUE, "vm: stack depth %d exceeds %d", depth, MDHIP_VM_STACK);
   }

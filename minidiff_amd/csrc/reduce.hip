@@ -279,7 +279,7 @@ struct HipExec {
     const bool rows_ok = n_red >= 256 && n_out < (1ll << 30);
     const bool cols_ok = pl.nk >= 1 && pl.kx[pl.nk - 1] == 1 && n_out >= 64;
     if (cols_ok && (!rows_ok || n_out >= 1024)) {
-      if constexpr (sizeof(Tacc) >= 4 && std::is_same<Tacc, To>::value) {
+      if constexpr (sizeof(Tacc) >= 4 && md_same<Tacc, To>::value) {
         constexpr int V = 16 / sizeof(Tacc);
         const bool vec_ok = pl.nk == 1 && pl.nr == 1 && pl.ko[0] == 1 && x->dtype == md_dtype_of<Tacc>::value &&
                             (n_out % V) == 0 && (pl.rx[0] % V) == 0 && ((uintptr_t)x->data & 15) == 0 &&

@@ -12,22 +12,26 @@ untouched; it simply sees arrays.
 Default is eager (one kernel per backend call, the reference's execution model),
 and bench.py reports the eager figure unless ``--lazy`` is given.
 
-Bounds of a fused program (include/mdhip.h): 48 postfix instructions, 8 distinct
-leaf arrays, 16 constants, operand stack depth 4. A tree that would exceed them
-materialises its larger operand first. Values are computed in ONE float type per
-program (float32 or float64 — whatever NumPy's loop resolution gave each op);
-bool results travel as 0/1. Integer loops are never fused.
+Bounds of a fused program (include/mdhip.h): 48 instructions, 8 distinct leaf
+arrays, operand stack depth 4. Operators whose operand is a leaf array or a
+constant carry it inside the instruction, so a chain costs one instruction per
+operator. A tree that would exceed the bounds materialises its larger operand
+first. Values are computed in ONE float type per program (float32 or float64 —
+whatever NumPy's loop resolution gave each op); bool results travel as 0/1.
+Integer loops are never fused.
 """
 from __future__ import annotations
 
 from . import _capi
+from ._capi import VM_BINARY, VM_PUSH, VM_SRC_CONST, VM_SRC_LEAF, VM_SRC_STACK, VM_UNARY, VM_WHERE, vm_ctrl
 
-LEAF, CONST, UNARY, BINARY, WHERE = 0, 1, 2, 3, 4
-MAX_INSTR, MAX_LEAVES, MAX_CONSTS, MAX_DEPTH = 40, 8, 16, 4
+LEAF, CONST, UNARY, BINARY, WHERE = range(5)
+MAX_INSTR, MAX_LEAVES, MAX_DEPTH = 44, 8, 4
 
 
 class Expr:
-    """Node of a pending expression. `cdt` is the program's float type code (F32/F64)."""
+    """Node of a pending expression. `cdt` is the program's float type code (F32/F64);
+    `n` / `depth` are the instruction count and stack need of its emitted form."""
 
     __slots__ = ("kind", "code", "args", "n", "depth", "leaves", "cdt")
 
@@ -44,19 +48,37 @@ def const(value, cdt):
     return Expr(CONST, 0, float(value), 1, 1, {}, cdt)
 
 
+def _simple(e) -> bool:
+    return e.kind == LEAF or e.kind == CONST
+
+
 def combine(kind, code, parts, cdt):
-    """Postfix cost of evaluating `parts` left to right then applying the operator."""
-    n = 1
-    depth = 0
     leaves = {}
-    for i, p in enumerate(parts):
-        n += p.n
-        d = p.depth + i
-        if d > depth:
-            depth = d
+    for p in parts:
         if p.leaves:
             leaves.update(p.leaves)
-    return Expr(kind, code, tuple(parts), n, depth, leaves, cdt)
+    if kind == UNARY:
+        (a,) = parts
+        return Expr(kind, code, (a,), a.n + 1, a.depth, leaves, cdt)
+    if kind == BINARY:
+        a, b = parts
+        sa, sb = _simple(a), _simple(b)
+        if sa and sb:
+            if a.kind == CONST and b.kind == CONST:      # two immediates: push one, fuse the other
+                n, depth = 2, 1
+            else:
+                n, depth = 1, 1
+        elif sb:
+            n, depth = a.n + 1, a.depth
+        elif sa:
+            n, depth = b.n + 1, b.depth
+        else:
+            n, depth = a.n + b.n + 1, max(a.depth, b.depth + 1)
+        return Expr(kind, code, (a, b), n, depth, leaves, cdt)
+    c, a, b = parts  # WHERE: all three go through the stack
+    n = c.n + a.n + b.n + 1
+    depth = max(c.depth, a.depth + 1, b.depth + 2)
+    return Expr(kind, code, (c, a, b), n, depth, leaves, cdt)
 
 
 def fits(e: Expr) -> bool:
@@ -64,45 +86,75 @@ def fits(e: Expr) -> bool:
 
 
 def emit(e: Expr):
-    """-> (kinds, args, leaf arrays, consts)."""
-    kinds, args, leaves, consts = [], [], [], []
-    leaf_ix, const_ix = {}, {}
+    """-> (ctrl words, immediates, leaf arrays)."""
+    ctrl, imm, leaves = [], [], []
+    leaf_ix = {}
+
+    def lix(arr):
+        k = id(arr)
+        if k not in leaf_ix:
+            leaf_ix[k] = len(leaves)
+            leaves.append(arr)
+        return leaf_ix[k]
+
+    def src(x):
+        """(source kind, leaf index, immediate) of a simple operand."""
+        if x.kind == LEAF:
+            return VM_SRC_LEAF, lix(x.args), 0.0
+        return VM_SRC_CONST, 0, x.args
+
+    def put(word, value=0.0):
+        ctrl.append(word)
+        imm.append(value)
 
     def walk(x):
-        if x.kind == LEAF:
-            k = id(x.args)
-            if k not in leaf_ix:
-                leaf_ix[k] = len(leaves)
-                leaves.append(x.args)
-            kinds.append(LEAF)
-            args.append(leaf_ix[k])
-        elif x.kind == CONST:
-            if x.args not in const_ix:
-                const_ix[x.args] = len(consts)
-                consts.append(x.args)
-            kinds.append(CONST)
-            args.append(const_ix[x.args])
+        if _simple(x):
+            s, l, v = src(x)
+            put(vm_ctrl(VM_PUSH, 0, 0, 0, s, l), v)
+        elif x.kind == UNARY:
+            walk(x.args[0])
+            put(vm_ctrl(VM_UNARY, x.code))
+        elif x.kind == BINARY:
+            a, b = x.args
+            sa, sb = _simple(a), _simple(b)
+            if sa and sb and a.kind == CONST and b.kind == CONST:
+                walk(a)
+                s, l, v = src(b)
+                put(vm_ctrl(VM_BINARY, x.code, VM_SRC_STACK, 0, s, l), v)
+            elif sa and sb:
+                s1, l1, v1 = src(a)
+                s2, l2, v2 = src(b)
+                put(vm_ctrl(VM_BINARY, x.code, s1, l1, s2, l2), v1 if s1 == VM_SRC_CONST else v2)
+            elif sb:
+                walk(a)
+                s, l, v = src(b)
+                put(vm_ctrl(VM_BINARY, x.code, VM_SRC_STACK, 0, s, l), v)
+            elif sa:
+                walk(b)
+                s, l, v = src(a)
+                put(vm_ctrl(VM_BINARY, x.code, s, l, VM_SRC_STACK, 0), v)
+            else:
+                walk(a)
+                walk(b)
+                put(vm_ctrl(VM_BINARY, x.code, VM_SRC_STACK, 0, VM_SRC_STACK, 0))
         else:
             for p in x.args:
                 walk(p)
-            kinds.append(x.kind)
-            args.append(x.code)
+            put(vm_ctrl(VM_WHERE))
 
     walk(e)
-    return kinds, args, leaves, consts
+    return ctrl, imm, leaves
 
 
 def build_program(e: Expr, shape):
-    kinds, args, leaves, consts = emit(e)
-    if len(kinds) > _capi.VM_MAX_INSTR or len(leaves) > _capi.VM_MAX_LEAVES or len(consts) > _capi.VM_MAX_CONSTS:
+    ctrl, imm, leaves = emit(e)
+    if len(ctrl) > _capi.VM_MAX_INSTR or len(leaves) > _capi.VM_MAX_LEAVES:
         raise ValueError("fused program exceeds the interpreter's limits")
     prog = _capi.VmProgram()
-    prog.n_instr, prog.n_leaves, prog.n_consts, prog.compute_dtype = len(kinds), len(leaves), len(consts), e.cdt
-    for i, (k, a) in enumerate(zip(kinds, args)):
-        prog.kind[i] = k
-        prog.arg[i] = a
-    for i, c in enumerate(consts):
-        prog.consts[i] = c
+    prog.n_instr, prog.n_leaves, prog.compute_dtype = len(ctrl), len(leaves), e.cdt
+    for i, (c, v) in enumerate(zip(ctrl, imm)):
+        prog.ctrl[i] = c
+        prog.imm[i] = v
     for i, arr in enumerate(leaves):
         prog.leaves[i] = arr.desc(shape)
     return prog, leaves

@@ -280,7 +280,8 @@ template <class T> static T host_vm_at(const mdhip_vm_program *pr, const MdVmIte
   }
   HostVmLoader<T> ld{pr, offs};
   T r[1];
-  md_vm_run<T, 1>(pr->n_instr, pr->kind, pr->arg, pr->consts, ld, r);
+  MdVmFetchDirect fetch{pr->ctrl, pr->imm};
+  md_vm_run<T, 1>(pr->n_instr, fetch, ld, r);
   if (out_off) *out_off = offs[MDHIP_VM_MAX_LEAVES];
   return r[0];
 }
@@ -346,6 +347,11 @@ int mdhip_vm_reduce(const mdhip_vm_program *pr, int op, const mdhip_array *shape
 #undef MD_VMR
   return md_fail(MDHIP_EVALUE, "vm_reduce: reduce op %d is not fused", op);
 }
+
+int mdhip_vm_jit_probe(const mdhip_vm_program *, int, int, int, char *, size_t) {
+  return md_fail(MDHIP_ERUNTIME, "the CPU test double has no run-time compiler");
+}
+int mdhip_vm_jit_stats(int64_t stats[2]) { stats[0] = stats[1] = 0; return MDHIP_OK; }
 
 // data-parallel entry points: the double has no collective; world size 1 only.
 int mdhip_comm_get_unique_id(uint8_t uid[MDHIP_UID_BYTES]) { memset(uid, 0, MDHIP_UID_BYTES); return MDHIP_OK; }
