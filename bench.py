@@ -163,6 +163,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        if torch.cuda.is_available():  # device_count() alone does not touch the GPU; set_device binds torch to OUR card
+            torch.cuda.set_device(local_rank)
 
     from minidiff_amd import _capi, workloads, dp
     from minidiff_amd.hip_backend import HipBackendTable
@@ -206,7 +208,6 @@ def main():
             except Exception as e:  # communicator could not be built: same data path via torch's RCCL
                 print(f"[rank {rank}] direct RCCL communicator failed ({e}); using torch.distributed nccl", file=sys.stderr)
         if comm is None:
-            torch.cuda.set_device(local_rank)
             comm = dp.TorchComm(rank, world, dist, torch)
             comm_kind = "rccl-torch"
     sync = dp.GradSync(md, state["params"] if args.workload == "cfg4" else state["params"][:1], comm)

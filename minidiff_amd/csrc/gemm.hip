@@ -40,16 +40,16 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-// Tile loaders for a ROWS x BK operand tile, 256 threads, 16 B per thread per pass.
+// Tile loaders for a ROWS x BK operand tile, NT threads, 16 B per thread per pass.
 // KC = the operand's k axis is the contiguous one in memory (row-major A, or B given as Bt).
-template <int ROWS, int BK, bool KC, bool EDGE>
+template <int ROWS, int BK, int NT, bool KC, bool EDGE>
 __device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t rs, int64_t ks, int64_t row0, int64_t k0,
-                                          int64_t rows, int64_t K, f32x4 (&r)[ROWS * BK / 1024]) {
-  constexpr int PASSES = ROWS * BK / 1024;
+                                          int64_t rows, int64_t K, f32x4 (&r)[ROWS * BK / (4 * NT)]) {
+  constexpr int PASSES = ROWS * BK / (4 * NT);
   constexpr int TPR = BK / 4;            // KC: threads per row
-  constexpr int RPP = 256 / TPR;         // KC: rows per pass
+  constexpr int RPP = NT / TPR;          // KC: rows per pass
   constexpr int TPK = ROWS / 4;          // !KC: threads per k-row
-  constexpr int KPP = 256 / TPK;         // !KC: k-rows per pass
+  constexpr int KPP = NT / TPK;          // !KC: k-rows per pass
   const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < PASSES; ++i) {
@@ -67,10 +67,10 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t r
     }
   }
 }
-template <int ROWS, int BK, bool KC>
-__device__ __forceinline__ void store_tile(float (*S)[ROWS + LDP], const f32x4 (&r)[ROWS * BK / 1024]) {
-  constexpr int PASSES = ROWS * BK / 1024;
-  constexpr int TPR = BK / 4, RPP = 256 / TPR, TPK = ROWS / 4, KPP = 256 / TPK;
+template <int ROWS, int BK, int NT, bool KC>
+__device__ __forceinline__ void store_tile(float (*S)[ROWS + LDP], const f32x4 (&r)[ROWS * BK / (4 * NT)]) {
+  constexpr int PASSES = ROWS * BK / (4 * NT);
+  constexpr int TPR = BK / 4, RPP = NT / TPR, TPK = ROWS / 4, KPP = NT / TPK;
   const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < PASSES; ++i) {
@@ -85,10 +85,11 @@ __device__ __forceinline__ void store_tile(float (*S)[ROWS + LDP], const f32x4 (
   }
 }
 
-// BM x BN block tile, BK k-step, 4 waves as 2 x 2, each wave (WTM*32) x (WTN*32).
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool EDGE>
-__global__ void __launch_bounds__(256) k_gemm_f32_mfma(GemmArgs g) {
-  constexpr int WTM = BM / 64, WTN = BN / 64;  // MFMA tiles per wave along m / n
+// BM x BN block tile, BK k-step, WM x WN waves, each wave (WTM*32) x (WTN*32).
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool EDGE>
+__global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_mfma(GemmArgs g) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);  // MFMA tiles per wave along m / n
   __shared__ float As[2][BK][BM + LDP];
   __shared__ float Bs[2][BK][BN + LDP];
 
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32_mfma(GemmArgs g) {
   float *C = g.C + bz * g.c_bs;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l32 = lane & 31, h = lane >> 5;
 
   f32x16 acc[WTM][WTN];
@@ -115,20 +116,20 @@ __global__ void __launch_bounds__(256) k_gemm_f32_mfma(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  f32x4 ra[BM * BK / 1024], rb[BN * BK / 1024];
+  f32x4 ra[BM * BK / (4 * NT)], rb[BN * BK / (4 * NT)];
   const int64_t nk = (g.K + BK - 1) / BK;
   // A tile rows = m (row stride a_ms), B tile rows = n (row stride b_ns)
   // Pipeline: LDS buffer `cur` holds tile kt, registers hold tile kt+1 (landed), and
   // inside the MFMA stream of tile kt the wave (step 0/1) writes tile kt+1 to the
   // other LDS buffer and (step 2) issues the global loads of tile kt+2 - so staging
   // costs no MFMA time of its own and the loads have ~6 steps (>3000 cycles) to land.
-  load_tile<BM, BK, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, 0, g.M, g.K, ra);
-  load_tile<BN, BK, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, 0, g.N, g.K, rb);
-  store_tile<BM, BK, A_KC>(As[0], ra);
-  store_tile<BN, BK, B_KC>(Bs[0], rb);
+  load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, 0, g.M, g.K, ra);
+  load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, 0, g.N, g.K, rb);
+  store_tile<BM, BK, NT, A_KC>(As[0], ra);
+  store_tile<BN, BK, NT, B_KC>(Bs[0], rb);
   if (nk > 1) {
-    load_tile<BM, BK, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, BK, g.M, g.K, ra);
-    load_tile<BN, BK, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, BK, g.N, g.K, rb);
+    load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, BK, g.M, g.K, ra);
+    load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, BK, g.N, g.K, rb);
   }
   __syncthreads();
 
@@ -149,11 +150,11 @@ __global__ void __launch_bounds__(256) k_gemm_f32_mfma(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < WTN; ++j) fb[c ^ 1][j] = Bs[cur][kk + 2 + h][wn * (WTN * 32) + j * 32 + l32];
       }
-      if (kk == 0 && more) store_tile<BM, BK, A_KC>(As[cur ^ 1], ra);
-      if (kk == 2 && more) store_tile<BN, BK, B_KC>(Bs[cur ^ 1], rb);
+      if (kk == 0 && more) store_tile<BM, BK, NT, A_KC>(As[cur ^ 1], ra);
+      if (kk == 2 && more) store_tile<BN, BK, NT, B_KC>(Bs[cur ^ 1], rb);
       if (kk == 4 && more2) {
-        load_tile<BM, BK, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 2) * BK, g.M, g.K, ra);
-        load_tile<BN, BK, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 2) * BK, g.N, g.K, rb);
+        load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 2) * BK, g.M, g.K, ra);
+        load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 2) * BK, g.N, g.K, rb);
       }
       // pin the order: staging and prefetch are issued ahead of this step's MFMAs
       __builtin_amdgcn_sched_barrier(0);
@@ -208,18 +209,19 @@ __global__ void __launch_bounds__(256) k_gemm_generic(MdGemm g) {
   if (row < g.M && col < g.N) C[row * g.c_ms + col * g.c_ns] = acc;
 }
 
-template <int BM, int BN, int BK, bool A_KC, bool B_KC>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC>
 static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
   ga.tiles_m = (int)((ga.M + BM - 1) / BM);
   ga.tiles_n = (int)((ga.N + BN - 1) / BN);
   edge = edge || (ga.M % BM) || (ga.N % BN) || (ga.K % BK);
   dim3 grid((unsigned)(ga.tiles_m * ga.tiles_n), 1, (unsigned)batch);
-  if (edge) k_gemm_f32_mfma<BM, BN, BK, A_KC, B_KC, true><<<grid, 256, 0, md_stream()>>>(ga);
-  else k_gemm_f32_mfma<BM, BN, BK, A_KC, B_KC, false><<<grid, 256, 0, md_stream()>>>(ga);
+  if (edge) k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, true><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
+  else k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, false><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
   return MD_LAUNCH_CHECK("matmul(f32 mfma)");
 }
 
-enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_128x128x32, CFG_COUNT };
+enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_128x128x32, CFG_256x128x16_8W, CFG_256x256x16_8W,
+       CFG_COUNT };
 
 static int pick_cfg(const GemmArgs &ga, int64_t batch) {
   if (const char *e = getenv("MDHIP_GEMM_CFG")) {  // experiments only
@@ -239,11 +241,13 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch) {
 template <bool A_KC, bool B_KC>
 static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
   switch (pick_cfg(ga, batch)) {
-    case CFG_64x64x16: return launch_cfg<64, 64, 16, A_KC, B_KC>(ga, batch, edge);
-    case CFG_128x64x16: return launch_cfg<128, 64, 16, A_KC, B_KC>(ga, batch, edge);
-    case CFG_256x128x16: return launch_cfg<256, 128, 16, A_KC, B_KC>(ga, batch, edge);
-    case CFG_128x128x32: return launch_cfg<128, 128, 32, A_KC, B_KC>(ga, batch, edge);
-    default: return launch_cfg<128, 128, 16, A_KC, B_KC>(ga, batch, edge);
+    case CFG_64x64x16: return launch_cfg<64, 64, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
+    case CFG_128x64x16: return launch_cfg<128, 64, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
+    case CFG_256x128x16: return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
+    case CFG_128x128x32: return launch_cfg<128, 128, 32, 2, 2, A_KC, B_KC>(ga, batch, edge);
+    case CFG_256x128x16_8W: return launch_cfg<256, 128, 16, 4, 2, A_KC, B_KC>(ga, batch, edge);
+    case CFG_256x256x16_8W: return launch_cfg<256, 256, 16, 4, 2, A_KC, B_KC>(ga, batch, edge);
+    default: return launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
   }
 }
 
