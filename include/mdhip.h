@@ -214,6 +214,13 @@ int mdhip_gather(const mdhip_index_plan *plan, const void *src, int dtype,
 int mdhip_scatter(const mdhip_index_plan *plan, void *dst, int dtype,
                   const mdhip_array *val, int mode);
 
+/* Positions of the non-zero elements of a CONTIGUOUS array, ascending flat order
+ * (np.flatnonzero; serves boolean-mask keys and np.argwhere, numpy.py:24,73-75).
+ * Two calls: count first (SYNCHRONISES, the result size is data dependent), then
+ * fill `out_flat` (int64[count]). */
+int mdhip_nonzero_count(const mdhip_array *x, int64_t *count_out);
+int mdhip_nonzero_fill(const mdhip_array *x, int64_t count, int64_t *out_flat);
+
 /* ======================= fused expressions (opt-in lazy mode) ============== */
 /* One pass over HBM for a whole elementwise expression, optionally ending in a
  * reduction (the "fused elementwise + reduce-to-shape backward" of the north

@@ -111,6 +111,8 @@ _PROTOTYPES = {
     "mdhip_matmul": [_P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc)],
     "mdhip_gather": [_P(IndexPlan), C.c_void_p, C.c_int, _P(ArrayDesc)],
     "mdhip_scatter": [_P(IndexPlan), C.c_void_p, C.c_int, _P(ArrayDesc), C.c_int],
+    "mdhip_nonzero_count": [_P(ArrayDesc), _P(C.c_int64)],
+    "mdhip_nonzero_fill": [_P(ArrayDesc), C.c_int64, C.c_void_p],
     "mdhip_vm_eval": [_P(VmProgram), _P(ArrayDesc)],
     "mdhip_vm_reduce": [_P(VmProgram), C.c_int, _P(ArrayDesc), _P(ArrayDesc), C.c_uint32],
     "mdhip_vm_jit_probe": [_P(VmProgram), C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t],

@@ -186,9 +186,113 @@ static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, c
   }
 }
 
+// ---- nonzero: per-block counts -> exclusive scan -> ordered compaction ------------------
+constexpr int NZ_CHUNK = 2048;  // elements per block (256 threads x 8 consecutive elements)
+
+template <class T>
+__global__ void __launch_bounds__(MD_BLOCK) k_nz_count(const T *x, int64_t n, int64_t *block_counts) {
+  __shared__ int wsum[MD_BLOCK / 64];
+  const int64_t base = (int64_t)blockIdx.x * NZ_CHUNK + (int64_t)threadIdx.x * 8;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (base + j < n && x[base + j] != (T)0) ++c;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = (int64_t)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+// exclusive scan of the block counts by one block (blocks <= a few 10^5: sequential chunks per lane)
+__global__ void __launch_bounds__(MD_BLOCK) k_nz_scan(int64_t *counts, int64_t nb, int64_t *total) {
+  __shared__ int64_t part[MD_BLOCK];
+  const int64_t per = (nb + MD_BLOCK - 1) / MD_BLOCK;
+  const int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+  int64_t s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += counts[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t run = 0;
+    for (int t = 0; t < MD_BLOCK; ++t) { const int64_t v = part[t]; part[t] = run; run += v; }
+    *total = run;
+  }
+  __syncthreads();
+  int64_t run = part[threadIdx.x];
+  for (int64_t i = lo; i < hi; ++i) { const int64_t v = counts[i]; counts[i] = run; run += v; }
+}
+template <class T>
+__global__ void __launch_bounds__(MD_BLOCK) k_nz_fill(const T *x, int64_t n, const int64_t *block_offsets, int64_t *out) {
+  __shared__ int tcount[MD_BLOCK];
+  const int64_t base = (int64_t)blockIdx.x * NZ_CHUNK + (int64_t)threadIdx.x * 8;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (base + j < n && x[base + j] != (T)0) ++c;
+  tcount[threadIdx.x] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {  // 256-entry exclusive scan
+    int run = 0;
+    for (int t = 0; t < MD_BLOCK; ++t) { const int v = tcount[t]; tcount[t] = run; run += v; }
+  }
+  __syncthreads();
+  int64_t pos = block_offsets[blockIdx.x] + tcount[threadIdx.x];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (base + j < n && x[base + j] != (T)0) out[pos++] = base + j;
+}
+
+template <class T> static int nz_run(const mdhip_array *x, int64_t n, int64_t *count_out, int64_t *out_flat) {
+  hipStream_t st = md_stream();
+  const int64_t nb = (n + NZ_CHUNK - 1) / NZ_CHUNK;
+  void *counts = nullptr, *total = nullptr;
+  MD_TRY(mdhip_alloc((size_t)(nb + 1) * 8, &counts));
+  MD_TRY(mdhip_alloc(8, &total));
+  k_nz_count<T><<<(unsigned)nb, MD_BLOCK, 0, st>>>((const T *)x->data, n, (int64_t *)counts);
+  k_nz_scan<<<1, MD_BLOCK, 0, st>>>((int64_t *)counts, nb, (int64_t *)total);
+  int rc = MD_LAUNCH_CHECK("nonzero(count)");
+  if (rc == MDHIP_OK && out_flat) {
+    k_nz_fill<T><<<(unsigned)nb, MD_BLOCK, 0, st>>>((const T *)x->data, n, (const int64_t *)counts, out_flat);
+    rc = MD_LAUNCH_CHECK("nonzero(fill)");
+  }
+  if (rc == MDHIP_OK && count_out) {
+    rc = md_hip_check(hipMemcpyAsync(count_out, total, 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync(count)");
+    if (rc == MDHIP_OK) rc = md_hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
+  }
+  mdhip_free(counts);
+  mdhip_free(total);
+  return rc;
+}
+static int nz_dispatch(const mdhip_array *x, int64_t *count_out, int64_t *out_flat) {
+  MD_TRY(md_check_array(x, "nonzero x"));
+  int64_t n = 1, acc = 1;
+  for (int d = x->ndim - 1; d >= 0; --d) {
+    if (x->shape[d] != 1 && x->strides[d] != acc) return md_fail(MDHIP_EVALUE, "nonzero: operand must be C-contiguous");
+    acc *= x->shape[d];
+  }
+  n = acc;
+  if (n == 0) { if (count_out) *count_out = 0; return MDHIP_OK; }
+  if ((n + NZ_CHUNK - 1) / NZ_CHUNK > 0x7fffffff) return md_fail(MDHIP_EVALUE, "nonzero: operand too large");
+  switch (x->dtype) {
+    case MDHIP_BOOL: return nz_run<uint8_t>(x, n, count_out, out_flat);
+    case MDHIP_I32: return nz_run<int32_t>(x, n, count_out, out_flat);
+    case MDHIP_I64: return nz_run<int64_t>(x, n, count_out, out_flat);
+    case MDHIP_F32: return nz_run<float>(x, n, count_out, out_flat);
+    case MDHIP_F64: return nz_run<double>(x, n, count_out, out_flat);
+  }
+  return md_fail(MDHIP_ETYPE, "nonzero: bad dtype");
+}
+
 }  // namespace
 
 extern "C" {
+
+int mdhip_nonzero_count(const mdhip_array *x, int64_t *count_out) { return nz_dispatch(x, count_out, nullptr); }
+int mdhip_nonzero_fill(const mdhip_array *x, int64_t count, int64_t *out_flat) {
+  if (count == 0) return MDHIP_OK;
+  if (!out_flat) return md_fail(MDHIP_EVALUE, "nonzero: null output");
+  return nz_dispatch(x, nullptr, out_flat);
+}
 
 int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const mdhip_array *out) {
   MD_TRY(md_check_plan(pl));

@@ -1581,11 +1581,36 @@ def split(ary, indices_or_sections, axis=0):
 # =============================================================================
 # indexing (bit-exact data movement)
 # =============================================================================
-def _nonzero_host(mask: DeviceArray):
-    """bool mask -> tuple of int64 index arrays. Index *preparation* only: the
-    positions are computed from a D2H copy of the mask, the payload never leaves
-    the device."""
-    return tuple(asarray(ix.astype(np.int64)) for ix in np.nonzero(mask.get()))
+def flatnonzero(a) -> "DeviceArray":
+    """Ascending flat positions of the non-zero elements (int64), computed on the device
+    (count -> scan -> ordered compaction; one host sync for the data-dependent size)."""
+    a = asarray(a)
+    if not a.is_c_contiguous:
+        a = copy(a)
+    cnt = C.c_int64()
+    _lib().nonzero_count(a.desc(), C.byref(cnt))
+    res = DeviceArray.empty((cnt.value,), np.int64)
+    if cnt.value:
+        _lib().nonzero_fill(a.desc(), cnt.value, res.ptr)
+    return res
+
+
+def _unravel(flat: "DeviceArray", shape) -> tuple:
+    """flat int64 positions -> one index array per axis of `shape` (device integer arithmetic)."""
+    out = []
+    rem = flat
+    for n in reversed(shape[1:]):
+        out.append(mod(rem, n))
+        rem = floor_divide(rem, n)
+    out.append(rem)
+    return tuple(reversed(out))
+
+
+def nonzero(a) -> tuple:
+    a = asarray(a)
+    if a.ndim == 0:
+        raise ValueError("Calling nonzero on 0d arrays is not allowed. Use np.atleast_1d(scalar).nonzero() instead.")
+    return _unravel(flatnonzero(a), a.shape)
 
 
 def _parse_key(a: DeviceArray, key):
@@ -1637,7 +1662,7 @@ def _parse_key(a: DeviceArray, key):
             ax0 = builtins_sum(1 for e in entries if e[0] != "new")
             if m.shape != a.shape[ax0:ax0 + m.ndim]:
                 raise IndexError(f"boolean index did not match indexed array along axis {ax0}; size of axis is {a.shape[ax0]} but size of corresponding boolean axis is {m.shape[0]}")
-            for ix in _nonzero_host(m):
+            for ix in nonzero(m):
                 entries.append(("adv", ix))
             has_adv = True
         elif isinstance(k, DeviceArray):
@@ -1886,23 +1911,37 @@ def put_along_axis(arr, indices, values, axis):
     del keep
 
 
-# ---- index utilities computed from host copies of (small) index data ----------
+# ---- index utilities (device integer arithmetic) ---------------------------------------
 def argwhere(a):
     a = asarray(a)
-    return asarray(np.argwhere(a.get()))
+    if a.ndim == 0:
+        a = reshape(a, (1,))
+        return reshape(stack(list(nonzero(a)), axis=1), (-1, 0))
+    return stack(list(nonzero(a)), axis=1)
 
 
 def isin(element, test_elements, **kw):
-    e = element.get() if isinstance(element, DeviceArray) else element
-    t = test_elements.get() if isinstance(test_elements, DeviceArray) else (
-        _to_host_nested(test_elements) if isinstance(test_elements, (list, tuple)) else test_elements)
-    return asarray(np.isin(e, t, **kw))
+    if kw:
+        raise TypeError("isin: only the default options are supported on the device")
+    e = asarray(element)
+    t = ravel(asarray(test_elements))
+    if t.size == 0:
+        return zeros(e.shape, dtype=np.bool_)
+    eq = equal(expand_dims(e, e.ndim), reshape(t, (1,) * e.ndim + (t.size,)))
+    return any(eq, axis=e.ndim)
 
 
-def unravel_index(indices, shape, **kw):
-    i = indices.get() if isinstance(indices, DeviceArray) else indices
-    out = np.unravel_index(i, shape, **kw)
-    return tuple(asarray(np.asarray(o)) for o in out)
+def unravel_index(indices, shape, order="C"):
+    if order != "C":
+        raise ValueError("unravel_index: only order='C' is supported on the device")
+    idx = asarray(indices)
+    if idx.dtype.kind not in "iu":
+        raise TypeError("only int indices permitted")
+    shape = _normalize_shape(shape)
+    total = _prod(shape)
+    if idx.size and (py_bool(any(less(idx, 0)).item()) or py_bool(any(greater_equal(idx, total)).item())):
+        raise ValueError(f"index is out of bounds for array with size {total}")
+    return _unravel(idx if idx.dtype == np.int64 else astype(idx, np.int64), shape)
 
 
 def materialize(a):

@@ -348,6 +348,17 @@ int mdhip_vm_reduce(const mdhip_vm_program *pr, int op, const mdhip_array *shape
   return md_fail(MDHIP_EVALUE, "vm_reduce: reduce op %d is not fused", op);
 }
 
+static int64_t host_nz(const mdhip_array *x, int64_t *out) {
+  int64_t n = 1;
+  for (int d = 0; d < x->ndim; ++d) n *= x->shape[d];
+  int64_t c = 0;
+  for (int64_t i = 0; i < n; ++i)
+    if (md_load<uint8_t>(x->data, x->dtype, i)) { if (out) out[c] = i; ++c; }
+  return c;
+}
+int mdhip_nonzero_count(const mdhip_array *x, int64_t *count_out) { *count_out = host_nz(x, nullptr); return MDHIP_OK; }
+int mdhip_nonzero_fill(const mdhip_array *x, int64_t, int64_t *out_flat) { host_nz(x, out_flat); return MDHIP_OK; }
+
 int mdhip_vm_jit_probe(const mdhip_vm_program *, int, int, int, char *, size_t) {
   return md_fail(MDHIP_ERUNTIME, "the CPU test double has no run-time compiler");
 }

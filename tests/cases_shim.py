@@ -343,6 +343,33 @@ def case_indexing(nd):
     check("gather/large", nd.asarray(big)[nd.asarray(keys)], big[keys], exact=True)
 
 
+def case_index_utils(nd):
+    rng = np.random.default_rng(30)
+    m = rng.integers(0, 3, (5, 7, 3)) > 1
+    dm = nd.asarray(m)
+    for got, exp in zip(nd.nonzero(dm), np.nonzero(m)):
+        check("nonzero", got, exp)
+    check("argwhere", nd.argwhere(dm), np.argwhere(m))
+    check("argwhere/float", nd.argwhere(nd.asarray(m * 1.5)), np.argwhere(m * 1.5))
+    check("argwhere/none", nd.argwhere(nd.asarray(np.zeros((3, 2)))), np.argwhere(np.zeros((3, 2))))
+    big = rng.integers(0, 5, (70001,)) == 0          # several compaction blocks, ragged tail
+    check("flatnonzero/big", nd.flatnonzero(nd.asarray(big)), np.flatnonzero(big))
+    x = rng.standard_normal((5, 7, 3)).astype(np.float32)
+    check("bool-mask getitem", nd.asarray(x)[dm], x[m], exact=True)
+    check("bool-mask partial", nd.asarray(x)[nd.asarray(m[:, :, 0])], x[m[:, :, 0]], exact=True)
+    xi = rng.integers(0, 10, (4, 6))
+    check("isin", nd.isin(nd.asarray(xi), [1, 3, 7]), np.isin(xi, [1, 3, 7]))
+    check("isin/arr", nd.isin(nd.asarray(xi), nd.asarray(np.array([2, 9]))), np.isin(xi, np.array([2, 9])))
+    flat = rng.integers(0, 5 * 7 * 3, (11,))
+    for got, exp in zip(nd.unravel_index(nd.asarray(flat), (5, 7, 3)), np.unravel_index(flat, (5, 7, 3))):
+        check("unravel_index", got, exp)
+    try:
+        nd.unravel_index(nd.asarray(np.array([105])), (5, 7, 3))
+        raise AssertionError("out-of-range flat index must raise ValueError")
+    except ValueError:
+        pass
+
+
 def case_inplace(nd):
     x, y = _data(np.float32, (2, 3, 4), 24), _data(np.float32, (3, 1), 25)
     w, dw = x.copy(), nd.asarray(x.copy())
@@ -371,7 +398,8 @@ def case_inplace(nd):
         pass
     m, dm = _data(np.float32, (4, 4), 27), None
     dm = nd.asarray(m.copy())
-    m @= m.copy(); dm @= nd.asarray(m_copy) if False else dm.copy()
+    m @= m.copy()
+    dm @= dm.copy()
     check("imatmul", dm, m, rtol=1e-5)
 
 

@@ -62,7 +62,7 @@ def test_matmul_cpu(lib, on_gpu, dtype): _run(lib, on_gpu, False, cs.case_matmul
 def test_matmul_gpu(lib, on_gpu, dtype): _run(lib, on_gpu, True, cs.case_matmul, dtype)
 
 SINGLE = ["case_unary_int", "case_reduce_large", "case_argreduce", "case_layout", "case_matmul_mfma", "case_where_clip",
-          "case_indexing", "case_inplace", "case_errors"]
+          "case_indexing", "case_index_utils", "case_inplace", "case_errors"]
 
 @pytest.mark.parametrize("case", SINGLE)
 def test_case_cpu(lib, on_gpu, case): _run(lib, on_gpu, False, getattr(cs, case))
