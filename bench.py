@@ -157,11 +157,17 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["MDHIP_DEVICE"] = str(local_rank)
 
+    # MDHIP_BENCH_FORCE_DIST=1 runs the N>1 code path (process group, ncclUniqueId exchange, RCCL
+    # communicator, per-sweep all-reduce, max-over-ranks timing) at world size 1 — the only way to
+    # rehearse it on a one-GPU box
+    force_dist = os.environ.get("MDHIP_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
     dist = torch = None
-    if world > 1:
+    if use_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         if torch.cuda.is_available():  # device_count() alone does not touch the GPU; set_device binds torch to OUR card
             torch.cuda.set_device(local_rank)
@@ -200,7 +206,7 @@ def main():
 
     comm = None
     comm_kind = "none"
-    if world > 1 and args.workload in ("cfg2", "cfg4"):
+    if use_dist and args.workload in ("cfg2", "cfg4"):
         if args.comm == "rccl":
             try:
                 comm = dp.RcclComm(rank, world, dist)
@@ -210,7 +216,7 @@ def main():
         if comm is None:
             comm = dp.TorchComm(rank, world, dist, torch)
             comm_kind = "rccl-torch"
-    sync = dp.GradSync(md, state["params"] if args.workload == "cfg4" else state["params"][:1], comm)
+    sync = dp.GradSync(md, state["params"] if args.workload == "cfg4" else state["params"][:1], comm, force=force_dist)
 
     def sweep():
         step()
@@ -218,7 +224,7 @@ def main():
 
     def barrier():
         lib.sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -233,7 +239,7 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -310,11 +316,11 @@ def main():
                 "cfg3": f"cfg3: sum((sin(x)*y)**2).backward(), N={n} fp32" + (" [lazy fusion]" if args.lazy else " [eager: 11 kernels]"),
                 "cfg4": f"cfg4: sum(relu(X@W+b)).backward(), global batch {n} x 4096 -> 4096, row-sharded",
                 "cfg5": f"cfg5: second order on {n}x{n} matmul, 5 GEMMs"}[args.workload],
-                "parallelism": f"dp{world}", "collective": comm_kind, "allreduce_bytes": sync.nbytes if world > 1 else 0},
+                "parallelism": f"dp{world}", "collective": comm_kind, "allreduce_bytes": sync.nbytes if use_dist else 0},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

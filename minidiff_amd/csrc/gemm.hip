@@ -221,7 +221,7 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
 }
 
 enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_128x128x32, CFG_256x128x16_8W, CFG_256x256x16_8W,
-       CFG_COUNT };
+       CFG_256x256x16_4W, CFG_COUNT };
 
 static int pick_cfg(const GemmArgs &ga, int64_t batch) {
   if (const char *e = getenv("MDHIP_GEMM_CFG")) {  // experiments only
@@ -247,6 +247,7 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
     case CFG_128x128x32: return launch_cfg<128, 128, 32, 2, 2, A_KC, B_KC>(ga, batch, edge);
     case CFG_256x128x16_8W: return launch_cfg<256, 128, 16, 4, 2, A_KC, B_KC>(ga, batch, edge);
     case CFG_256x256x16_8W: return launch_cfg<256, 256, 16, 4, 2, A_KC, B_KC>(ga, batch, edge);
+    case CFG_256x256x16_4W: return launch_cfg<256, 256, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
     default: return launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
   }
 }

@@ -94,14 +94,14 @@ class HostComm:
 class GradSync:
     """Sums `.grad` of the given parameters across ranks after each backward()."""
 
-    def __init__(self, md, params, comm):
-        self.md, self.params, self.comm = md, list(params), comm
+    def __init__(self, md, params, comm, force=False):
+        self.md, self.params, self.comm, self.force = md, list(params), comm, force
         self.bucket = None
         self.nbytes = int(sum(p.size * np.dtype(p.dtype).itemsize for p in self.params))
 
     def __call__(self):
         B = self.md.backend
-        if self.comm is None or self.comm.world == 1:
+        if self.comm is None or (self.comm.world == 1 and not self.force):
             return
         grads = [p.grad for p in self.params]
         if any(g is None for g in grads):

@@ -64,3 +64,24 @@ def test_rccl_single_rank_gpu(lib, on_gpu):
     comm.allreduce_sum_(di)
     assert np.array_equal(di.get(), np.arange(1000))
     comm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("comm", ["rccl", "torch"])
+@pytest.mark.parametrize("workload", ["cfg2", "cfg4"])
+def test_bench_distributed_path_on_one_gpu(on_gpu, comm, workload):
+    """bench.py's N>1 branch end to end at world size 1 (MDHIP_BENCH_FORCE_DIST): process group,
+    ncclUniqueId exchange, RCCL communicator (direct, and through torch.distributed), the
+    per-sweep all-reduce of the gradient (bucketed for cfg4) and max-over-ranks timing."""
+    assert on_gpu
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MDHIP_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--workload", workload, "--size", "512", "--no-cpu-baseline", "--comm", comm],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["config"]["collective"] == ("rccl-direct" if comm == "rccl" else "rccl-torch"), line["config"]
+    assert line["config"]["allreduce_bytes"] > 0 and line["value"] > 0
