@@ -17,8 +17,6 @@ the CPU.
 """
 from __future__ import annotations
 
-from builtins import bool as py_bool
-
 import numpy as np
 
 from . import ndarray as nd

@@ -85,65 +85,72 @@ def fits(e: Expr) -> bool:
     return e.n <= MAX_INSTR and e.depth <= MAX_DEPTH and len(e.leaves) <= MAX_LEAVES
 
 
-def emit(e: Expr):
-    """-> (ctrl words, immediates, leaf arrays)."""
-    ctrl, imm, leaves = [], [], []
-    leaf_ix = {}
+class _Emitter:
+    """Postfix emission state. A plain object with methods — NOT nested recursive closures,
+    which would form a reference cycle and keep the leaf arrays (HBM blocks) alive until
+    Python's cyclic GC runs."""
 
-    def lix(arr):
-        k = id(arr)
-        if k not in leaf_ix:
-            leaf_ix[k] = len(leaves)
-            leaves.append(arr)
-        return leaf_ix[k]
+    __slots__ = ("ctrl", "imm", "leaves", "leaf_ix")
 
-    def src(x):
+    def __init__(self):
+        self.ctrl, self.imm, self.leaves, self.leaf_ix = [], [], [], {}
+
+    def src(self, x):
         """(source kind, leaf index, immediate) of a simple operand."""
         if x.kind == LEAF:
-            return VM_SRC_LEAF, lix(x.args), 0.0
+            k = id(x.args)
+            ix = self.leaf_ix.get(k)
+            if ix is None:
+                ix = self.leaf_ix[k] = len(self.leaves)
+                self.leaves.append(x.args)
+            return VM_SRC_LEAF, ix, 0.0
         return VM_SRC_CONST, 0, x.args
 
-    def put(word, value=0.0):
-        ctrl.append(word)
-        imm.append(value)
+    def put(self, word, value=0.0):
+        self.ctrl.append(word)
+        self.imm.append(value)
 
-    def walk(x):
+    def walk(self, x):
         if _simple(x):
-            s, l, v = src(x)
-            put(vm_ctrl(VM_PUSH, 0, 0, 0, s, l), v)
+            s, l, v = self.src(x)
+            self.put(vm_ctrl(VM_PUSH, 0, 0, 0, s, l), v)
         elif x.kind == UNARY:
-            walk(x.args[0])
-            put(vm_ctrl(VM_UNARY, x.code))
+            self.walk(x.args[0])
+            self.put(vm_ctrl(VM_UNARY, x.code))
         elif x.kind == BINARY:
             a, b = x.args
             sa, sb = _simple(a), _simple(b)
             if sa and sb and a.kind == CONST and b.kind == CONST:
-                walk(a)
-                s, l, v = src(b)
-                put(vm_ctrl(VM_BINARY, x.code, VM_SRC_STACK, 0, s, l), v)
+                self.walk(a)
+                s, l, v = self.src(b)
+                self.put(vm_ctrl(VM_BINARY, x.code, VM_SRC_STACK, 0, s, l), v)
             elif sa and sb:
-                s1, l1, v1 = src(a)
-                s2, l2, v2 = src(b)
-                put(vm_ctrl(VM_BINARY, x.code, s1, l1, s2, l2), v1 if s1 == VM_SRC_CONST else v2)
+                s1, l1, v1 = self.src(a)
+                s2, l2, v2 = self.src(b)
+                self.put(vm_ctrl(VM_BINARY, x.code, s1, l1, s2, l2), v1 if s1 == VM_SRC_CONST else v2)
             elif sb:
-                walk(a)
-                s, l, v = src(b)
-                put(vm_ctrl(VM_BINARY, x.code, VM_SRC_STACK, 0, s, l), v)
+                self.walk(a)
+                s, l, v = self.src(b)
+                self.put(vm_ctrl(VM_BINARY, x.code, VM_SRC_STACK, 0, s, l), v)
             elif sa:
-                walk(b)
-                s, l, v = src(a)
-                put(vm_ctrl(VM_BINARY, x.code, s, l, VM_SRC_STACK, 0), v)
+                self.walk(b)
+                s, l, v = self.src(a)
+                self.put(vm_ctrl(VM_BINARY, x.code, s, l, VM_SRC_STACK, 0), v)
             else:
-                walk(a)
-                walk(b)
-                put(vm_ctrl(VM_BINARY, x.code, VM_SRC_STACK, 0, VM_SRC_STACK, 0))
+                self.walk(a)
+                self.walk(b)
+                self.put(vm_ctrl(VM_BINARY, x.code, VM_SRC_STACK, 0, VM_SRC_STACK, 0))
         else:
             for p in x.args:
-                walk(p)
-            put(vm_ctrl(VM_WHERE))
+                self.walk(p)
+            self.put(vm_ctrl(VM_WHERE))
 
-    walk(e)
-    return ctrl, imm, leaves
+
+def emit(e: Expr):
+    """-> (ctrl words, immediates, leaf arrays)."""
+    em = _Emitter()
+    em.walk(e)
+    return em.ctrl, em.imm, em.leaves
 
 
 def build_program(e: Expr, shape):

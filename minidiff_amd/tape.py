@@ -23,7 +23,6 @@ baseline need the reference's arithmetic. The tape itself does no arithmetic.
 from __future__ import annotations
 
 import types
-from builtins import bool as py_bool
 from contextvars import ContextVar
 from math import prod as _pyprod
 
