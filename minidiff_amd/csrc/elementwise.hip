@@ -68,13 +68,42 @@ template <class T> struct FastOp {
 template <class Tc> struct md_storage { using type = Tc; };
 template <> struct md_storage<uint8_t> { using type = b8; };
 
-template <class T, class Tc>
+// Streams larger than the 256 MiB Infinity Cache are touched once: a non-temporal hint on
+// the 16-B loads and stores keeps them from allocating in L2/MALL (+10-12 % on 400 MB
+// operands: profiles/r1_streaming_nt_ab.log). Smaller operands keep normal caching so that
+// the consumer of a just-written intermediate (cfg4's z, masks) still hits the cache.
+template <bool NT, class V> __device__ __forceinline__ V md_ld_stream(const V *p) {
+  if constexpr (sizeof(V) == 16 && NT) {
+    {
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(p));
+      V v;
+      __builtin_memcpy(&v, &t, 16);
+      return v;
+    }
+  }
+  return *p;
+}
+template <bool NT, class V> __device__ __forceinline__ void md_st_stream(V *p, const V &v) {
+  if constexpr (sizeof(V) == 16 && NT) {
+    {
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      i32x4 t;
+      __builtin_memcpy(&t, &v, 16);
+      __builtin_nontemporal_store(t, reinterpret_cast<i32x4 *>(p));
+      return;
+    }
+  }
+  *p = v;
+}
+
+template <bool NT = false, class T, class Tc>
 __device__ __forceinline__ void md_fast_load(const FastOp<T> &o, Tc s, int64_t row, int64_t c, Tc (&r)[4]) {
   if (o.p == nullptr) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) r[j] = s;
   } else if (o.is) {
-    MdVec<T, 4> v = *reinterpret_cast<const MdVec<T, 4> *>(o.p + row * o.os + c);
+    MdVec<T, 4> v = md_ld_stream<NT>(reinterpret_cast<const MdVec<T, 4> *>(o.p + row * o.os + c));
 #pragma unroll
     for (int j = 0; j < 4; ++j) r[j] = md_cast<Tc>(v.v[j]);
   } else {
@@ -103,7 +132,7 @@ __device__ __forceinline__ void md_row_col(int64_t v, int64_t nv, int64_t rows, 
   }
 }
 
-template <class F, class Tc, class To, class Tx>
+template <class F, class Tc, class To, class Tx, bool NT>
 __global__ void __launch_bounds__(MD_BLOCK) k_unary_fast(FastOp<Tx> x, Tc sx, To *out, int64_t rows, int64_t inner) {
   const int64_t nv = inner >> 2, total = rows * nv;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -113,11 +142,11 @@ __global__ void __launch_bounds__(MD_BLOCK) k_unary_fast(FastOp<Tx> x, Tc sx, To
     md_row_col(v, nv, rows, row, cv);
     const int64_t c = cv << 2;
     Tc xv[4];
-    md_fast_load(x, sx, row, c, xv);
+    md_fast_load<NT>(x, sx, row, c, xv);
     MdVec<To, 4> o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o.v[j] = md_to_out<To>(F::apply(xv[j]));
-    *reinterpret_cast<MdVec<To, 4> *>(out + row * inner + c) = o;
+    md_st_stream<NT>(reinterpret_cast<MdVec<To, 4> *>(out + row * inner + c), o);
   }
   if (rows == 1) {
     const int64_t t0 = nv << 2;
@@ -125,7 +154,7 @@ __global__ void __launch_bounds__(MD_BLOCK) k_unary_fast(FastOp<Tx> x, Tc sx, To
   }
 }
 
-template <class F, class Tc, class To, class Ta, class Tb>
+template <class F, class Tc, class To, class Ta, class Tb, bool NT>
 __global__ void __launch_bounds__(MD_BLOCK) k_binary_fast(FastOp<Ta> a, FastOp<Tb> b, Tc sa, Tc sb, To *out, int64_t rows, int64_t inner) {
   const int64_t nv = inner >> 2, total = rows * nv;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -135,12 +164,12 @@ __global__ void __launch_bounds__(MD_BLOCK) k_binary_fast(FastOp<Ta> a, FastOp<T
     md_row_col(v, nv, rows, row, cv);
     const int64_t c = cv << 2;
     Tc xv[4], yv[4];
-    md_fast_load(a, sa, row, c, xv);
-    md_fast_load(b, sb, row, c, yv);
+    md_fast_load<NT>(a, sa, row, c, xv);
+    md_fast_load<NT>(b, sb, row, c, yv);
     MdVec<To, 4> o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o.v[j] = md_to_out<To>(F::apply(xv[j], yv[j]));
-    *reinterpret_cast<MdVec<To, 4> *>(out + row * inner + c) = o;
+    md_st_stream<NT>(reinterpret_cast<MdVec<To, 4> *>(out + row * inner + c), o);
   }
   if (rows == 1) {
     const int64_t t0 = nv << 2;
@@ -221,6 +250,16 @@ template <class T> static bool fast_operand(const MdIter &it, int k, const mdhip
   return true;
 }
 
+// non-temporal streaming when one launch touches more than the Infinity Cache can hold
+static int nt_for(int64_t bytes) {
+  static int mode = [] {
+    const char *e = getenv("MDHIP_NT");  // 0 = never, 1 = always, unset = by size
+    return e ? (e[0] == '0' ? 0 : 1) : -1;
+  }();
+  if (mode >= 0) return mode;
+  return bytes > ((int64_t)320 << 20);
+}
+
 struct HipExec {
   // ------------------------------------------------------------------ unary ----
   template <class F, class Tc, class To>
@@ -232,7 +271,9 @@ struct HipExec {
     FastOp<Tx> fx;
     if (fast_geom(it, 1, &g) && fast_aligned<To>(out->data) && fast_operand<Tx>(it, 0, x, g, &fx)) {
       const int64_t work = g.rows * (g.inner >> 2) + (g.rows == 1 ? 4 : 0);
-      k_unary_fast<F, Tc, To, Tx><<<md_grid_for(work), MD_BLOCK, 0, st>>>(fx, sx, (To *)out->data, g.rows, g.inner);
+      const int64_t bytes = g.rows * g.inner * (int64_t)(sizeof(To) + (fx.p && fx.is ? sizeof(Tx) : 0));
+      if (nt_for(bytes)) k_unary_fast<F, Tc, To, Tx, true><<<md_grid_for(work), MD_BLOCK, 0, st>>>(fx, sx, (To *)out->data, g.rows, g.inner);
+      else k_unary_fast<F, Tc, To, Tx, false><<<md_grid_for(work), MD_BLOCK, 0, st>>>(fx, sx, (To *)out->data, g.rows, g.inner);
       return MD_LAUNCH_CHECK("unary(fast)");
     }
     k_unary_generic<F, Tc, To><<<md_grid_for(it.total), MD_BLOCK, 0, st>>>(it, x->data, x->dtype, x->is_scalar, sx, (To *)out->data);
@@ -247,7 +288,9 @@ struct HipExec {
     FastOp<Tb> fb;
     if (!fast_operand<Ta>(it, 0, a, g, &fa) || !fast_operand<Tb>(it, 1, b, g, &fb)) return false;
     const int64_t work = g.rows * (g.inner >> 2) + (g.rows == 1 ? 4 : 0);
-    k_binary_fast<F, Tc, To, Ta, Tb><<<md_grid_for(work), MD_BLOCK, 0, md_stream()>>>(fa, fb, sa, sb, (To *)out->data, g.rows, g.inner);
+    const int64_t bytes = g.rows * g.inner * (int64_t)(sizeof(To) + (fa.p && fa.is ? sizeof(Ta) : 0) + (fb.p && fb.is ? sizeof(Tb) : 0));
+    if (nt_for(bytes)) k_binary_fast<F, Tc, To, Ta, Tb, true><<<md_grid_for(work), MD_BLOCK, 0, md_stream()>>>(fa, fb, sa, sb, (To *)out->data, g.rows, g.inner);
+    else k_binary_fast<F, Tc, To, Ta, Tb, false><<<md_grid_for(work), MD_BLOCK, 0, md_stream()>>>(fa, fb, sa, sb, (To *)out->data, g.rows, g.inner);
     *status = MD_LAUNCH_CHECK("binary(fast)");
     return true;
   }

@@ -355,7 +355,11 @@ template <class T> static int eval_typed(const mdhip_vm_program *pr, const mdhip
   const bool to_bool = out->dtype == MDHIP_BOOL;
   if (fast_geometry(it, pr->n_leaves, pr, true, &D, &rows, &inner) && al_for(out->data, out->dtype)) {
     if (jit::enabled() && it.total >= jit::min_elems()) {
-      if (hipFunction_t fn = jit::get(pr, jit::EVAL, 0, to_bool)) {
+      // the streamed bytes of this launch: output + distinct vector leaves
+      int64_t bytes = it.total * (int64_t)md_dtype_size(out->dtype);
+      for (int l = 0; l < pr->n_leaves; ++l)
+        if (D.leaf[l].is) bytes += it.total * (int64_t)md_dtype_size(pr->leaves[l].dtype);
+      if (hipFunction_t fn = jit::get(pr, jit::EVAL, 0, to_bool, bytes > ((int64_t)320 << 20))) {
         jit::JArgs A;
         jit::fill_args(&A, pr, D);
         A.out = out->data; A.rows = rows; A.inner = inner;
@@ -388,7 +392,11 @@ static int reduce_typed(const mdhip_vm_program *pr, int rop, const mdhip_array *
   if (!fast_geometry(it, pr->n_leaves, pr, false, &D, &rows, &inner)) return md_fail(MDHIP_EVALUE, "vm_reduce: geometry not supported");
   if (((uintptr_t)out->data & 15) != 0) return md_fail(MDHIP_EVALUE, "vm_reduce: unaligned output");
   if (mask == all) {
-    hipFunction_t fn = (jit::enabled() && it.total >= jit::min_elems()) ? jit::get(pr, jit::RED_ALL, rop, false) : nullptr;
+    int64_t rbytes = 0;
+    for (int l = 0; l < pr->n_leaves; ++l)
+      if (D.leaf[l].is) rbytes += it.total * (int64_t)md_dtype_size(pr->leaves[l].dtype);
+    hipFunction_t fn = (jit::enabled() && it.total >= jit::min_elems())
+                           ? jit::get(pr, jit::RED_ALL, rop, false, rbytes > ((int64_t)320 << 20)) : nullptr;
     const int64_t work = fn ? rows * (inner >> 2) + (rows == 1 ? 4 : 0) : (rows * (inner >> 2) + VG - 1) / VG + (rows == 1 ? 4 : 0);
     const int grid = md_grid_for(work);
     void *partial = nullptr;

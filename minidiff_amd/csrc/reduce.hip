@@ -44,7 +44,20 @@ template <class R, class T> __device__ __forceinline__ T md_block_reduce(T v, T 
 }
 
 // ------------------------------------------------------------------- rows ------
-template <class R, class Tacc, class Tdst, bool FINAL>
+// 16-B load with a non-temporal hint (operands larger than the Infinity Cache are read once)
+template <bool NT, class V> __device__ __forceinline__ V md_ld_once(const V *p) {
+  if constexpr (NT && sizeof(V) == 16) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(p));
+    V v;
+    __builtin_memcpy(&v, &t, 16);
+    return v;
+  } else {
+    return *p;
+  }
+}
+
+template <class R, class Tacc, class Tdst, bool FINAL, bool NT = false>
 __global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows(MdRedPlan pl, const void *x, int xdt, int64_t splits, Tdst *dst) {
   __shared__ Tacc smem[MD_BLOCK / 64];
   const int64_t b = blockIdx.x;
@@ -74,8 +87,8 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows(MdRedPlan pl, const vo
       const MdVec<Tacc, V> *pv = reinterpret_cast<const MdVec<Tacc, V> *>(p + head);
       int64_t i = lane0;
       for (; i + step < nvec; i += 2 * step) {
-        MdVec<Tacc, V> t = pv[i];
-        MdVec<Tacc, V> u = pv[i + step];
+        MdVec<Tacc, V> t = md_ld_once<NT>(pv + i);
+        MdVec<Tacc, V> u = md_ld_once<NT>(pv + i + step);
 #pragma unroll
         for (int j = 0; j < V; ++j) { a2[j] = R::combine(a2[j], t.v[j]); a3[j] = R::combine(a3[j], u.v[j]); }
       }
@@ -339,7 +352,10 @@ struct HipExec {
       }
       void *partial = nullptr;
       MD_TRY(mdhip_alloc((size_t)(splits * n_out) * sizeof(Tacc), &partial));
-      k_reduce_rows<R, Tacc, Tacc, false><<<(unsigned)(n_out * splits), MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, splits, (Tacc *)partial);
+      if (n_red * n_out * (int64_t)sizeof(Tacc) > ((int64_t)320 << 20))
+        k_reduce_rows<R, Tacc, Tacc, false, true><<<(unsigned)(n_out * splits), MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, splits, (Tacc *)partial);
+      else
+        k_reduce_rows<R, Tacc, Tacc, false><<<(unsigned)(n_out * splits), MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, splits, (Tacc *)partial);
       k_finish_rows<R, Tacc, To><<<(unsigned)n_out, MD_BLOCK, 0, st>>>(pl, (const Tacc *)partial, splits, (To *)out->data);
       int rc = MD_LAUNCH_CHECK("reduce(rows,split)");
       mdhip_free(partial);
