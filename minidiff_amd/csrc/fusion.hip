@@ -8,10 +8,11 @@
 // program interpreted per element (csrc/md_vm.h) — the leaves are read once, the
 // result is written (or reduced) once: HBM-bound at the *fused* byte count.
 //
-// Kernels (all wave-uniform control flow; 16 elements per lane per interpreter pass on
-// the vector path, which amortises the per-step fetch/decode/branch cost):
+// Interpreter kernels (all wave-uniform control flow; they serve arrays below the
+// run-time-compilation threshold and are the fallback when hiprtc is unavailable —
+// arrays of >= 2^18 elements run the specialised kernels of fusion_jit.inc):
 //   k_vm_eval_fast     (rows, inner) geometry: leaves contiguous / row- or column-
-//                      broadcast / stride-0, 16-B loads+stores, 16 elements per lane per pass
+//                      broadcast / stride-0, 16-B loads+stores
 //   k_vm_eval_generic  any <=8-D strides, one element per lane
 //   k_vm_reduce_all    full reduction of the program's value (grid-strided sweep,
 //                      block partials + finishing block) — fused "...sum()"
@@ -28,7 +29,7 @@ extern "C" int mdhip_free(void *);
 
 namespace {
 
-constexpr int VG = 4;        // 16-B vector groups per lane per interpreter pass
+constexpr int VG = 1;        // 16-B vector groups per lane per interpreter pass (large arrays take the compiled path)
 constexpr int VW = 4 * VG;   // lanes of the operand stack per thread
 
 // leaf load for VG element groups of the (rows, inner) geometry: VG independent 16-B loads

@@ -5,9 +5,8 @@
 // register arrays of W lanes (W = 4 on the vector path; static indices only, so
 // nothing spills to scratch). To keep the per-instruction overhead below the HBM
 // time of the data it touches:
-//   * one interpreter step covers W lanes per thread (16 on the device: four 16-B
-//     vector groups, so a leaf operand is four independent loads in flight) — the
-//     fetch / decode / branch cost of a step is per wave-instruction, not per lane;
+//   * one interpreter step covers W lanes per thread (one 16-B vector group on the
+//     device's vector path);
 //   * most instructions are operand-fused (s0 = op(s0, leaf|const)), so a chain
 //     costs one instruction per operator and no stack traffic;
 //   * an instruction is 16 bytes {ctrl, pad, imm(double)}; Fetch supplies it — the
@@ -106,8 +105,7 @@ template <class T, int W> MD_HD void md_vm_binary(int op, const T (&A)[W], const
 }
 #undef MD_VM_B
 
-// Loader concept: void operator()(int leaf, T (&dst)[W]) — loads W lanes of leaf `leaf`
-// (on the device W = 16: four 16-B vector groups per lane, four loads in flight).
+// Loader concept: void operator()(int leaf, T (&dst)[W]) — loads W lanes of leaf `leaf`.
 template <class T, int W, class Loader>
 MD_HD void md_vm_operand(uint32_t src, uint32_t leaf, double imm, Loader &load, T (&d)[W]) {
   if (src == MDHIP_VM_SRC_CONST) {
@@ -120,8 +118,6 @@ MD_HD void md_vm_operand(uint32_t src, uint32_t leaf, double imm, Loader &load, 
 }
 
 // Fetch concept: void operator()(int pc, uint32_t &ctrl, double &imm); prefetch(int pc).
-// The cost of one interpreter step (fetch, decode, a handful of taken scalar branches)
-// is per wave-instruction, so W lanes per step amortise it W-fold.
 template <class T, int W, class Fetch, class Loader>
 MD_HD void md_vm_run(const int32_t n_instr, Fetch &fetch, Loader &load, T (&s0)[W]) {
   T s1[W], s2[W], s3[W];
