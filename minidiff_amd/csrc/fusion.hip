@@ -286,7 +286,11 @@ __global__ void __launch_bounds__(MD_BLOCK) k_vm_reduce_cols(MdVmDev P, int64_t 
   }
   T tot[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) tot[j] = R::combine(R::combine(a[j], a[4 + j]), R::combine(a[8 + j], a[12 + j]));
+  for (int j = 0; j < 4; ++j) {
+    tot[j] = a[j];
+#pragma unroll
+    for (int g = 1; g < VG; ++g) tot[j] = R::combine(tot[j], a[4 * g + j]);
+  }
   if (ry > 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) smem[ry - 1][cx][j] = tot[j];

@@ -142,3 +142,21 @@ def _sweeps(nd, on_gpu, want_gpu):
 def test_sweeps_cpu(lazy_nd, on_gpu): _sweeps(lazy_nd, on_gpu, False)
 @gpu
 def test_sweeps_gpu(lazy_nd, on_gpu): _sweeps(lazy_nd, on_gpu, True)
+
+
+@gpu
+def test_interpreter_only_gpu(on_gpu):
+    """MDHIP_JIT=0 (read once per process): the lazy cases above through the built-in
+    interpreter kernels alone — the fallback when hiprtc is unavailable."""
+    assert on_gpu
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    if os.environ.get("MDHIP_JIT") == "0":
+        pytest.skip("already running interpreter-only")
+    env = dict(os.environ, MDHIP_JIT="0", MDHIP_LAZY="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_lazy_fusion.py"),
+                        os.path.join(here, "test_golden_device.py"), "-m", "gpu", "-q", "--no-header", "-p", "no:cacheprovider",
+                        "-k", "not interpreter_only"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
