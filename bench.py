@@ -289,7 +289,7 @@ def main():
             bytes_per_launch = 64 * n / 6
             ach = bytes_per_launch / (avg * 1e-3) / 1e9
             tot_ms = sum(sum(v) for v in kernel_ms.values())
-            traffic = pmc_mean(pmc, "k_binary_fast<BMul, float, float, float, float>") if not args.size else None
+            traffic = pmc_mean(pmc, "k_binary_fast<BMul, float, float, float, float") if not args.size else None
             roofline = {"bound": "hbm", "kernel": "k_binary_fast<BMul,f32>", "achieved": ach, "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                         "traffic_source": pmc.get("_source") if traffic else None,
