@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lazy", action="store_true",
                     help="opt-in lazy fusion of elementwise chains (minidiff_amd/lazy.py); default is eager")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one sweep into a hipGraph after warm-up and time K replays of it (N=1 only)")
     ap.add_argument("--comm", default=os.environ.get("MDHIP_COMM", "rccl"), choices=["rccl", "torch"])
     return ap.parse_args()
 
@@ -227,13 +229,31 @@ def main():
         if use_dist:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        sweep()
+    captured = None
+    if args.graph:
+        if use_dist:
+            raise SystemExit("--graph is a single-GPU mode (the gradient all-reduce is not captured)")
+        # single kernels cannot be bracketed inside a replay: the per-kernel durations the roofline
+        # needs come from the (eager, identical) warm-up sweeps instead
+        sweep()  # cold start (code object load, allocator growth) stays out of the kernel averages
+        timer.enabled = True
+        for _ in range(max(args.warmup, 1)):
+            sweep()
+        lib.sync()
+        timer.enabled = False
+        from minidiff_amd.graph import CapturedSweep
+        captured = CapturedSweep(step, warmup=0)
+        captured.replay()
+        run_one = captured.replay
+    else:
+        for _ in range(args.warmup):
+            sweep()
+        run_one = sweep
     barrier()
-    timer.enabled = True
+    timer.enabled = not args.graph
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sweep()
+        run_one()
     lib.sync()
     if torch is not None and torch.cuda.is_available():
         torch.cuda.synchronize()
@@ -304,6 +324,8 @@ def main():
 
     if comm is not None:
         comm.close()
+    if captured is not None:
+        captured.close()
     if rank == 0:
         n = args.size or {"cfg2": 4096, "cfg3": 100_000_000, "cfg4": 8192, "cfg5": 2048}[args.workload]
         line = {
@@ -316,7 +338,7 @@ def main():
                 "cfg3": f"cfg3: sum((sin(x)*y)**2).backward(), N={n} fp32" + (" [lazy fusion]" if args.lazy else " [eager: 11 kernels]"),
                 "cfg4": f"cfg4: sum(relu(X@W+b)).backward(), global batch {n} x 4096 -> 4096, row-sharded",
                 "cfg5": f"cfg5: second order on {n}x{n} matmul, 5 GEMMs"}[args.workload],
-                "parallelism": f"dp{world}", "collective": comm_kind, "allreduce_bytes": sync.nbytes if use_dist else 0},
+                "parallelism": f"dp{world}", "graph_replay": bool(args.graph), "collective": comm_kind, "allreduce_bytes": sync.nbytes if use_dist else 0},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -155,6 +155,20 @@ int mdhip_event_record(void *ev);
 int mdhip_event_elapsed_ms(void *start, void *stop, float *ms_out); /* SYNCHRONISES on stop */
 int mdhip_event_destroy(void *ev);
 
+/* ======================= hipGraph capture / replay ========================== */
+/* Capture everything enqueued on the library's stream between begin and end into a
+ * hipGraph and replay it with one launch (removes per-call host dispatch and launch
+ * gaps for repeated sweeps of small graphs). Device blocks allocated
+ * while capturing stay RESERVED for the graph (temporaries are recycled only inside
+ * it, results keep their addresses) until mdhip_graph_destroy, so a replay rewrites
+ * the very arrays the captured run returned. Calls that must synchronise (D2H,
+ * data-dependent sizes, index bounds checks, H2D uploads) are not capturable and fail
+ * with MDHIP_ERUNTIME; mdhip_graph_end must still be called (it aborts the capture). */
+int mdhip_graph_begin(void);
+int mdhip_graph_end(void **graph_out);
+int mdhip_graph_launch(void *graph);
+int mdhip_graph_destroy(void *graph);
+
 /* ======================= elementwise ====================================== */
 /* out = op(x). `out` describes freshly allocated (or in-place) memory with the
  * result dtype chosen by the caller from NumPy's type resolution. */

@@ -102,6 +102,10 @@ _PROTOTYPES = {
     "mdhip_event_record": [C.c_void_p],
     "mdhip_event_elapsed_ms": [C.c_void_p, C.c_void_p, _P(C.c_float)],
     "mdhip_event_destroy": [C.c_void_p],
+    "mdhip_graph_begin": [],
+    "mdhip_graph_end": [_P(C.c_void_p)],
+    "mdhip_graph_launch": [C.c_void_p],
+    "mdhip_graph_destroy": [C.c_void_p],
     "mdhip_unary": [C.c_int, _P(ArrayDesc), _P(ArrayDesc)],
     "mdhip_binary": [C.c_int, _P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc), C.c_int],
     "mdhip_where": [_P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc)],

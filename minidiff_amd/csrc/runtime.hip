@@ -23,12 +23,23 @@ std::string &md_err_slot() {
 }
 
 namespace {
+// A captured graph owns the blocks that were allocated while it was being captured:
+// they are recycled only among the graph's own temporaries (during capture) and are
+// never handed to anyone else until the graph is destroyed — replays write to the
+// addresses baked into the captured kernels.
+struct Graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  std::map<size_t, std::vector<void *>> free_lists;  // private pool
+};
 struct State {
   std::mutex mu;
   int device = -1;
   hipStream_t stream = nullptr;
   std::map<size_t, std::vector<void *>> free_lists;  // rounded size -> blocks
   std::unordered_map<void *, size_t> live;           // ptr -> rounded size
+  std::unordered_map<void *, Graph *> owner;         // blocks reserved for a graph (live or privately cached)
+  Graph *capturing = nullptr;
   int64_t in_use = 0, cached = 0, peak = 0, n_malloc = 0;
 };
 State &S() {
@@ -96,6 +107,18 @@ int mdhip_alloc(size_t nbytes, void **ptr_out) {
   size_t r = round_size(nbytes);
   std::lock_guard<std::mutex> lk(s.mu);
   void *p = nullptr;
+  if (s.capturing) {  // temporaries of the captured sweep recycle inside the graph's own pool first
+    auto pit = s.capturing->free_lists.find(r);
+    if (pit != s.capturing->free_lists.end() && !pit->second.empty()) {
+      p = pit->second.back();
+      pit->second.pop_back();
+      s.live[p] = r;
+      s.in_use += (int64_t)r;
+      if (s.in_use > s.peak) s.peak = s.in_use;
+      *ptr_out = p;
+      return MDHIP_OK;
+    }
+  }
   auto it = s.free_lists.find(r);
   if (it != s.free_lists.end() && !it->second.empty()) {
     p = it->second.back();
@@ -116,6 +139,7 @@ int mdhip_alloc(size_t nbytes, void **ptr_out) {
     ++s.n_malloc;
   }
   s.live[p] = r;
+  if (s.capturing) s.owner[p] = s.capturing;
   s.in_use += (int64_t)r;
   if (s.in_use > s.peak) s.peak = s.in_use;
   *ptr_out = p;
@@ -131,6 +155,18 @@ int mdhip_free(void *p) {
   size_t r = it->second;
   s.live.erase(it);
   s.in_use -= (int64_t)r;
+  auto ow = s.owner.find(p);
+  if (ow != s.owner.end()) {  // reserved for a graph: back to that graph's private pool only
+    ow->second->free_lists[r].push_back(p);
+    return MDHIP_OK;
+  }
+  if (s.capturing) {
+    // a pre-existing block released while capturing may be referenced by captured kernels:
+    // keep it reserved for the graph as well
+    s.owner[p] = s.capturing;
+    s.capturing->free_lists[r].push_back(p);
+    return MDHIP_OK;
+  }
   s.free_lists[r].push_back(p);
   s.cached += (int64_t)r;
   return MDHIP_OK;
@@ -183,6 +219,84 @@ int mdhip_event_elapsed_ms(void *a, void *b, float *ms) {
   return md_hip_check(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b), "hipEventElapsedTime");
 }
 int mdhip_event_destroy(void *ev) { return md_hip_check(hipEventDestroy((hipEvent_t)ev), "hipEventDestroy"); }
+
+// ============================ hipGraph ==========================================
+int mdhip_graph_begin(void) {
+  State &s = S();
+  if (!s.stream) return md_fail(MDHIP_ERUNTIME, "mdhip_init has not been called");
+  std::lock_guard<std::mutex> lk(s.mu);
+  if (s.capturing) return md_fail(MDHIP_ERUNTIME, "a capture is already in progress");
+  Graph *g = new Graph();
+  hipError_t e = hipStreamBeginCapture(s.stream, hipStreamCaptureModeRelaxed);
+  if (e != hipSuccess) {
+    delete g;
+    return md_hip_check(e, "hipStreamBeginCapture");
+  }
+  s.capturing = g;
+  return MDHIP_OK;
+}
+
+int mdhip_graph_end(void **graph_out) {
+  State &s = S();
+  std::lock_guard<std::mutex> lk(s.mu);
+  Graph *g = s.capturing;
+  if (!g) return md_fail(MDHIP_ERUNTIME, "no capture in progress");
+  s.capturing = nullptr;
+  hipError_t e = hipStreamEndCapture(s.stream, &g->graph);
+  if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    // an invalidated capture can leave the stream refusing work ("previous error during capture"):
+    // if it still reports a capture, continue on a fresh stream (nothing is in flight — the
+    // captured region never executed)
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    hipError_t q = hipStreamIsCapturing(s.stream, &st);
+    if (q != hipSuccess || st != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      hipStream_t fresh = nullptr;
+      if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) {
+        (void)hipStreamDestroy(s.stream);
+        (void)hipGetLastError();
+        s.stream = fresh;
+      }
+    }
+    // abort: hand every reserved block back to the general pool
+    for (auto it = s.owner.begin(); it != s.owner.end();) {
+      if (it->second == g) it = s.owner.erase(it); else ++it;
+    }
+    for (auto &kv : g->free_lists)
+      for (void *p : kv.second) { s.free_lists[kv.first].push_back(p); s.cached += (int64_t)kv.first; }
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    if (graph_out) *graph_out = nullptr;
+    return md_fail(MDHIP_ERUNTIME, "graph capture failed: %s (a call inside the captured region needed to synchronise?)", hipGetErrorString(e));
+  }
+  *graph_out = g;
+  return MDHIP_OK;
+}
+
+int mdhip_graph_launch(void *graph) {
+  Graph *g = (Graph *)graph;
+  if (!g || !g->exec) return md_fail(MDHIP_EVALUE, "graph_launch: null graph");
+  return md_hip_check(hipGraphLaunch(g->exec, md_stream()), "hipGraphLaunch");
+}
+
+int mdhip_graph_destroy(void *graph) {
+  Graph *g = (Graph *)graph;
+  if (!g) return MDHIP_OK;
+  State &s = S();
+  (void)hipStreamSynchronize(s.stream);
+  std::lock_guard<std::mutex> lk(s.mu);
+  for (auto it = s.owner.begin(); it != s.owner.end();) {
+    if (it->second == g) it = s.owner.erase(it); else ++it;   // still-live results become ordinary blocks
+  }
+  for (auto &kv : g->free_lists)
+    for (void *p : kv.second) { s.free_lists[kv.first].push_back(p); s.cached += (int64_t)kv.first; }
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+  return MDHIP_OK;
+}
 
 // ============================ RCCL ==============================================
 // One communicator per process. librccl is opened lazily so single-GPU runs never

@@ -211,7 +211,11 @@ class DeviceArray:
         dtype_code(arr.dtype)
         host = arr if arr.flags.c_contiguous else np.array(arr, order="C")  # (ascontiguousarray would promote 0-d to 1-d)
         out = DeviceArray.empty(host.shape, host.dtype)
-        if host.nbytes:
+        if host.size == 1:
+            # one element (a wrapped Python scalar): a fill launch instead of an upload — no stream
+            # synchronisation, and it stays capturable into a graph (graph.py)
+            _fill(out, host.reshape(()).item())
+        elif host.nbytes:
             _lib().h2d(out.ptr, host.ctypes.data, host.nbytes)
         return out
 

@@ -174,6 +174,15 @@ int mdhip_event_elapsed_ms(void *a, void *b, float *ms) {
 }
 int mdhip_event_destroy(void *ev) { delete (HostEvent *)ev; return MDHIP_OK; }
 
+// graphs: the double executes immediately, so "capture" records nothing and replay cannot
+// re-run anything; it only accepts the call sequence (tests of the Python wrapper's state
+// machine); numerical replay is covered on the GPU.
+static int g_host_capturing = 0;
+int mdhip_graph_begin(void) { if (g_host_capturing) return md_fail(MDHIP_ERUNTIME, "a capture is already in progress"); g_host_capturing = 1; return MDHIP_OK; }
+int mdhip_graph_end(void **g) { if (!g_host_capturing) return md_fail(MDHIP_ERUNTIME, "no capture in progress"); g_host_capturing = 0; *g = nullptr; return md_fail(MDHIP_ERUNTIME, "the CPU test double cannot replay graphs"); }
+int mdhip_graph_launch(void *) { return md_fail(MDHIP_ERUNTIME, "the CPU test double cannot replay graphs"); }
+int mdhip_graph_destroy(void *) { return MDHIP_OK; }
+
 int mdhip_unary(int op, const mdhip_array *x, const mdhip_array *out) { return md_unary_dispatch<HostExec>(op, x, out); }
 int mdhip_binary(int op, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out, int cdt) {
   return md_binary_dispatch<HostExec>(op, a, b, out, cdt);
