@@ -218,7 +218,8 @@ def main():
         if comm is None:
             comm = dp.TorchComm(rank, world, dist, torch)
             comm_kind = "rccl-torch"
-    sync = dp.GradSync(md, state["params"] if args.workload == "cfg4" else state["params"][:1], comm, force=force_dist)
+    sync = dp.GradSync(md, state["params"] if args.workload == "cfg4" else state["params"][:1], comm, force=force_dist,
+                       overlap=os.environ.get("MDHIP_DP_OVERLAP", "1") != "0")
 
     def sweep():
         step()
@@ -338,7 +339,8 @@ def main():
                 "cfg3": f"cfg3: sum((sin(x)*y)**2).backward(), N={n} fp32" + (" [lazy fusion]" if args.lazy else " [eager: 11 kernels]"),
                 "cfg4": f"cfg4: sum(relu(X@W+b)).backward(), global batch {n} x 4096 -> 4096, row-sharded",
                 "cfg5": f"cfg5: second order on {n}x{n} matmul, 5 GEMMs"}[args.workload],
-                "parallelism": f"dp{world}", "graph_replay": bool(args.graph), "collective": comm_kind, "allreduce_bytes": sync.nbytes if use_dist else 0},
+                "parallelism": f"dp{world}", "graph_replay": bool(args.graph), "collective": comm_kind, "allreduce_bytes": sync.nbytes if use_dist else 0,
+                "allreduce_overlapped_sweeps": sync.overlapped},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -296,6 +296,12 @@ int mdhip_vm_jit_stats(int64_t stats[2]);
 int mdhip_comm_get_unique_id(uint8_t uid[MDHIP_UID_BYTES]);
 int mdhip_comm_init(int nranks, int rank, const uint8_t uid[MDHIP_UID_BYTES]);
 int mdhip_comm_allreduce_sum(void *buf, size_t count, int dtype); /* in place, on the stream */
+/* Overlapped form: the collective is issued on a second stream, after
+ * everything enqueued so far on the compute stream, and runs beside the kernels enqueued
+ * next (the rest of backward). mdhip_comm_wait makes the compute stream wait for it; buf must
+ * not be released, read or written on the compute stream before that call. One in flight. */
+int mdhip_comm_allreduce_sum_async(void *buf, size_t count, int dtype);
+int mdhip_comm_wait(void);
 int mdhip_comm_destroy(void);
 
 #ifdef __cplusplus

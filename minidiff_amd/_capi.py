@@ -124,6 +124,8 @@ _PROTOTYPES = {
     "mdhip_comm_get_unique_id": [_P(C.c_uint8)],
     "mdhip_comm_init": [C.c_int, C.c_int, _P(C.c_uint8)],
     "mdhip_comm_allreduce_sum": [C.c_void_p, C.c_size_t, C.c_int],
+    "mdhip_comm_allreduce_sum_async": [C.c_void_p, C.c_size_t, C.c_int],
+    "mdhip_comm_wait": [],
     "mdhip_comm_destroy": [],
 }
 # every symbol include/mdhip.h declares (string-returning ones listed apart)

@@ -9,9 +9,15 @@ are summed across ranks in place on the device:
   * several        -> gradients are packed into one flat f32 bucket
                       ([W.grad || b.grad] = 16,781,312 floats for cfg4), one
                       collective, and the gradients become views of the bucket.
-The collective is ncclAllReduce(sum) issued by libmdhip on the same stream as
-the kernels (RCCL over xGMI; `mdhip_comm_*` in include/mdhip.h), so it is
-ordered after the last backward kernel without a host sync.
+The collective is ncclAllReduce(sum) issued by libmdhip (RCCL over xGMI;
+`mdhip_comm_*` in include/mdhip.h) without a host sync. With `overlap=True`
+(default) the tape reports each parameter gradient the moment it is final
+(`register_grad_ready_hook`; hooked inputs get their vjp first), and as soon as
+the whole bucket is final the collective goes out on a second
+stream while the compute stream carries on with the rest of backward (cfg2:
+B.grad's all-reduce runs beside the A.grad GEMM); `GradSync.__call__` at the end
+of the sweep makes the compute stream wait for it. Without hooks firing (or
+`overlap=False`) the collective is issued at that point on the compute stream.
 
 `torch.distributed` is used for rendezvous / barriers / the ncclUniqueId
 exchange only (gloo control plane). Communicators:
@@ -54,6 +60,18 @@ class RcclComm:
         nd._before_write(arr)
         self.lib.comm_allreduce_sum(arr.ptr, arr.size, nd.dtype_code(arr.dtype))
 
+    def allreduce_sum_async_(self, arr):
+        from . import ndarray as nd
+
+        if not arr.is_c_contiguous:
+            raise ValueError("allreduce needs a contiguous device buffer")
+        nd.materialize(arr)
+        nd._before_write(arr)
+        self.lib.comm_allreduce_sum_async(arr.ptr, arr.size, nd.dtype_code(arr.dtype))
+
+    def wait(self):
+        self.lib.comm_wait()
+
     def close(self):
         self.lib.comm_destroy()
 
@@ -94,15 +112,50 @@ class HostComm:
 class GradSync:
     """Sums `.grad` of the given parameters across ranks after each backward()."""
 
-    def __init__(self, md, params, comm, force=False):
+    def __init__(self, md, params, comm, force=False, overlap=True):
         self.md, self.params, self.comm, self.force = md, list(params), comm, force
         self.bucket = None
         self.nbytes = int(sum(p.size * np.dtype(p.dtype).itemsize for p in self.params))
+        self.active = not (comm is None or (comm.world == 1 and not force))
+        self.overlap = bool(overlap and self.active and hasattr(md, "register_grad_ready_hook"))
+        self._ready = set()
+        self._in_flight = False
+        self.overlapped = 0  # sweeps whose collective went out from inside backward()
+        if self.overlap:
+            for p in self.params:
+                md.register_grad_ready_hook(p, self._on_ready)
+
+    def _on_ready(self, tensor):
+        self._ready.add(id(tensor))
+        if len(self._ready) == len(self.params):
+            self._ready.clear()
+            self._reduce(asynchronous=True)
+            self._in_flight = True
+            self.overlapped += 1
+
+    def close(self):
+        if self.overlap:
+            for p in self.params:
+                self.md.remove_grad_ready_hook(p)
+            self.overlap = False
 
     def __call__(self):
-        B = self.md.backend
-        if self.comm is None or (self.comm.world == 1 and not self.force):
+        if not self.active:
             return
+        self._ready.clear()
+        if self._in_flight:  # issued from inside backward(): only join the streams
+            self._in_flight = False
+            wait = getattr(self.comm, "wait", None)
+            if wait is not None:
+                wait()
+            return
+        self._reduce(asynchronous=False)
+
+    def _reduce(self, asynchronous):
+        B = self.md.backend
+        allreduce = self.comm.allreduce_sum_
+        if asynchronous:
+            allreduce = getattr(self.comm, "allreduce_sum_async_", allreduce)
         grads = [p.grad for p in self.params]
         if any(g is None for g in grads):
             raise RuntimeError("GradSync: a parameter has no gradient (was backward() run?)")
@@ -111,7 +164,7 @@ class GradSync:
             if not _is_contiguous(raw):
                 raw = B.copy(raw)
                 self.params[0].grad = self.md.Tensor(raw)
-            self.comm.allreduce_sum_(raw)
+            allreduce(raw)
             return
         dt = grads[0].dtype
         total = sum(g.size for g in grads)
@@ -124,7 +177,7 @@ class GradSync:
             view[...] = B.reshape(g._data if g.dtype == dt else B.astype(g._data, dt), (n,))
             p.grad = self.md.Tensor(B.reshape(view, g.shape))
             pos += n
-        self.comm.allreduce_sum_(self.bucket)
+        allreduce(self.bucket)
 
 
 def _is_contiguous(raw) -> bool:

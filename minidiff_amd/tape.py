@@ -112,9 +112,18 @@ def build_engine(B, name: str = "engine"):
             for t in self.tensor_inputs:
                 t.graph_refs += 1
 
-        def push(self, grad):
-            """Chain rule for this node: evaluate each vjp, undo broadcasting, accumulate."""
-            for inp, vjp in zip(self.inputs, self.vjps):
+        def push(self, grad, pending=None):
+            """Chain rule for this node: evaluate each vjp, undo broadcasting, accumulate.
+            `pending` (only when gradient-ready hooks are registered, see
+            `register_grad_ready_hook`) counts the contributions each hooked leaf still
+            expects: hooked inputs are served first and their hook fires the moment the
+            last contribution has been accumulated, so a collective on that gradient
+            overlaps the vjps that remain."""
+            order = range(len(self.inputs))
+            if pending:
+                order = sorted(order, key=lambda i: id(self.inputs[i]) not in pending)  # stable: hooked first
+            for i in order:
+                inp, vjp = self.inputs[i], self.vjps[i]
                 if vjp is None or not isinstance(inp, Tensor) or not inp.allow_grad:
                     continue
                 kw = self.kwargs if self.pass_kwargs else {}
@@ -122,6 +131,11 @@ def build_engine(B, name: str = "engine"):
                 if g.shape != inp.shape:
                     g = E.unbroadcast(g, inp.shape)
                 inp.grad = g if inp.grad is None else inp.grad + g
+                if pending and id(inp) in pending:
+                    pending[id(inp)] -= 1
+                    if pending[id(inp)] == 0:
+                        del pending[id(inp)]
+                        E.grad_ready_hooks[id(inp)][1](inp)
 
         def backward(self, seed, retain_grads=False, cleanup_mode="prune", allow_higher_order=False, reset_grads=True):
             if cleanup_mode not in ("keep", "prune", "destroy"):
@@ -134,13 +148,20 @@ def build_engine(B, name: str = "engine"):
             if reset_grads:
                 for t in path:
                     t.grad = None
+            pending = None
+            if E.grad_ready_hooks:
+                pending = {}
+                for node in [self] + [t.op_node for t in path if not t.is_leaf]:
+                    for inp, vjp in zip(node.inputs, node.vjps):
+                        if vjp is not None and isinstance(inp, Tensor) and inp.allow_grad and id(inp) in E.grad_ready_hooks:
+                            pending[id(inp)] = pending.get(id(inp), 0) + 1
             with enable_grad(allow_higher_order):
-                self.push(seed)
+                self.push(seed, pending)
                 for t in reversed(path):
                     if t.is_leaf:
                         continue
                     node = t.op_node
-                    node.push(t.grad)
+                    node.push(t.grad, pending)
                     if not retain_grads:
                         t.grad = None
                     if cleanup_mode == "keep":
@@ -167,6 +188,19 @@ def build_engine(B, name: str = "engine"):
         return out
 
     E.OpNode = Node
+
+    # gradient-ready hooks (no reference counterpart: the data-parallel harness).
+    # id(tensor) -> (tensor, fn); fn(tensor) runs inside backward() as soon as tensor.grad is final
+    E.grad_ready_hooks = {}
+
+    def register_grad_ready_hook(tensor, fn):
+        E.grad_ready_hooks[id(tensor)] = (tensor, fn)
+
+    def remove_grad_ready_hook(tensor):
+        E.grad_ready_hooks.pop(id(tensor), None)
+
+    E.register_grad_ready_hook = register_grad_ready_hook
+    E.remove_grad_ready_hook = remove_grad_ready_hook
 
     # --------------------------------------------------------------- tensor ----
     class Tensor:

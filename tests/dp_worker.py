@@ -33,6 +33,7 @@ def main():
     sync = dp.GradSync(md, st["params"], comm)
     assert sync.nbytes == (24 * 40 + 40) * 4
     step()
+    assert sync.overlapped == 1  # the bucket went out from inside backward(), when its last member became final
     sync()
     for name in ("W", "b"):
         got, exp = st[name].grad.as_numpy(), full_state[name].grad.as_numpy()
@@ -47,10 +48,11 @@ def main():
 
     # cfg2: every rank has its own batch block A_r; B.grad = sum_r A_r^T @ G_r, one un-bucketed all-reduce
     st2, step2 = workloads.make_cfg2(md, n=48, rank=rank)
-    sync2 = dp.GradSync(md, st2["params"][:1], comm)
+    sync2 = dp.GradSync(md, st2["params"][:1], comm, overlap=False)
     step2()
     local = st2["B"].grad.as_numpy().copy()
     sync2()
+    assert sync2.overlapped == 0
     gathered = [torch.zeros(48, 48) for _ in range(world)]
     dist.all_gather(gathered, torch.from_numpy(local))
     exp = sum(g.numpy().astype(np.float64) for g in gathered)
@@ -58,6 +60,21 @@ def main():
     assert err < 1e-6, err
     # A.grad stays local (rows are independent)
     assert st2["A"].grad.shape == (48, 48)
+    a_local = st2["A"].grad.as_numpy().copy()
+    # overlapped form: B.grad's vjp is served first and its all-reduce is issued before A.grad's vjp runs
+    order = []
+    real = comm.allreduce_sum_
+    comm.allreduce_sum_ = lambda arr: (order.append("allreduce"), real(arr))[1]
+    sync3 = dp.GradSync(md, st2["params"][:1], comm)
+    step2()
+    assert sync3.overlapped == 1 and order == ["allreduce"]
+    sync3()
+    assert order == ["allreduce"]  # joined, not repeated
+    err = np.abs(st2["B"].grad.as_numpy() - exp).max() / np.abs(exp).max()
+    assert err < 1e-6, err
+    assert np.array_equal(st2["A"].grad.as_numpy(), a_local)
+    sync3.close()
+    comm.allreduce_sum_ = real
     dist.barrier()
     dist.destroy_process_group()
     print(f"DP-OK rank {rank}/{world}")

@@ -67,6 +67,35 @@ def test_rccl_single_rank_gpu(lib, on_gpu):
 
 
 @pytest.mark.gpu
+def test_overlapped_allreduce_single_rank_gpu(engines, on_gpu):
+    """The collective issued from inside backward() on the second stream (ready/done events), world
+    size 1: gradients equal the un-overlapped sweep bit for bit and the streams are joined."""
+    assert on_gpu
+    from minidiff_amd import dp, workloads
+    hip, _ = engines
+    comm = dp.RcclComm(0, 1)
+    try:
+        for maker, kw, names in ((workloads.make_cfg2, {"n": 384}, ("A", "B")),
+                                 (workloads.make_cfg4, {"batch": 256, "d_in": 192, "d_out": 160}, ("W", "b"))):
+            st, step = maker(hip, **kw)
+            step()
+            ref = {k: st[k].grad.as_numpy().copy() for k in names}
+            params = st["params"][:1] if maker is workloads.make_cfg2 else st["params"]
+            sync = dp.GradSync(hip, params, comm, force=True)
+            for _ in range(3):
+                step()
+                sync()
+            assert sync.overlapped == 3
+            for k in names:
+                np.testing.assert_array_equal(st[k].grad.as_numpy(), ref[k])
+            sync.close()
+            step()
+            assert sync.overlapped == 3  # hooks removed
+    finally:
+        comm.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("comm", ["rccl", "torch"])
 @pytest.mark.parametrize("workload", ["cfg2", "cfg4"])
 def test_bench_distributed_path_on_one_gpu(on_gpu, comm, workload):
@@ -85,3 +114,4 @@ def test_bench_distributed_path_on_one_gpu(on_gpu, comm, workload):
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["config"]["collective"] == ("rccl-direct" if comm == "rccl" else "rccl-torch"), line["config"]
     assert line["config"]["allreduce_bytes"] > 0 and line["value"] > 0
+    assert line["config"]["allreduce_overlapped_sweeps"] == 4  # every sweep's collective left from inside backward()
