@@ -292,14 +292,15 @@ def main():
                         "launches": len(durs), "avg_launch_ms": avg, "flop_per_launch": flop_per_launch,
                         "algorithmic_bytes_per_launch": 3 * 4 * (args.size or 4096) ** 2 if args.workload == "cfg2" else None}
     elif args.lazy:
-        # fused: one reduce pass over (x, y) for the loss, one pass per gradient (reads x, y; writes 4N)
+        # fused: one reduce pass over (x, y) for the loss (8N), one two-output pass for both
+        # gradients (reads x, y once, writes x.grad and y.grad: 16N) = SURVEY 8d's fused lower bound
         n = state["rows"]
-        fused_bytes = 32 * n
+        fused_bytes = 24 * n
         ach = fused_bytes / (ms_per_step * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_vm_reduce_all + 2 x k_vm_eval_fast (expression interpreter)",
+        roofline = {"bound": "hbm", "kernel": "k_fused (reduce) + k_fused (two-output eval), run-time specialised",
                     "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
                     "fused_algorithmic_bytes_per_sweep": fused_bytes, "eager_algorithmic_bytes_per_sweep": state["bytes"],
-                    "note": "achieved = fused bytes / whole-sweep time (3 launches); the eager figure (100N bytes) is not mixed in"}
+                    "note": "achieved = fused bytes / whole-sweep time (3 launches incl. the reduction's finish); the eager figure (100N bytes) is not mixed in"}
     else:
         # dominant kernel of the eager chain: the f32 multiply (6 of the 11 launches per sweep:
         # five read 2 x 4N and write 4N, the scaled stride-0 seed only writes 4N -> 64N bytes per sweep)

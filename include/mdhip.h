@@ -287,6 +287,12 @@ int mdhip_vm_reduce(const mdhip_vm_program *prog, int reduce_op, const mdhip_arr
  * reduce; needs no device), and counters {kernels compiled, kernels launched}. */
 int mdhip_vm_jit_probe(const mdhip_vm_program *prog, int kind, int reduce_op, int out_is_bool,
                        char *log, size_t log_capacity);
+/* outs[k][...] = progs[k](...) for n programs of ONE shape (e.g. the gradients of one
+ * backward sweep, which share their operands): with run-time specialisation available and
+ * 2..4 programs whose merged operand tables fit one launch, every distinct leaf is read once
+ * and all results are written in the same pass; otherwise exactly n mdhip_vm_eval calls. */
+int mdhip_vm_eval_multi(const mdhip_vm_program *progs, const mdhip_array *outs, int n);
+int mdhip_vm_jit_probe_multi(const mdhip_vm_program *progs, int n, char *log, size_t log_capacity);
 int mdhip_vm_jit_stats(int64_t stats[2]);
 
 /* ======================= data-parallel (RCCL over xGMI) =================== */

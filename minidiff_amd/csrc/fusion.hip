@@ -381,6 +381,86 @@ template <class T> static int eval_typed(const mdhip_vm_program *pr, const mdhip
   return MD_LAUNCH_CHECK("vm_eval(generic)");
 }
 
+// merge the leaf tables of n programs (identical descriptors share a slot) and give every
+// immediate its slot in the shared array; false if the bounds of one launch are exceeded
+static bool merge_programs(const mdhip_vm_program *progs, int n, jit::Multi *M, mdhip_vm_program *merged) {
+  if (n < 2 || n > 4) return false;
+  M->n = n;
+  memset(merged, 0, sizeof *merged);
+  merged->compute_dtype = progs[0].compute_dtype;
+  for (int k = 0; k < n; ++k) {
+    const mdhip_vm_program *pr = &progs[k];
+    if (pr->compute_dtype != progs[0].compute_dtype) return false;
+    M->pr[k] = pr;
+    for (int l = 0; l < pr->n_leaves; ++l) {
+      const mdhip_array &a = pr->leaves[l];
+      int slot = -1;
+      for (int m = 0; m < M->n_leaves && slot < 0; ++m) {
+        const mdhip_array &b = merged->leaves[m];
+        bool same = a.data == b.data && a.dtype == b.dtype && a.ndim == b.ndim;
+        for (int d = 0; same && d < a.ndim; ++d) same = a.shape[d] == b.shape[d] && a.strides[d] == b.strides[d];
+        if (same) slot = m;
+      }
+      if (slot < 0) {
+        if (M->n_leaves == MDHIP_VM_MAX_LEAVES) return false;
+        slot = M->n_leaves++;
+        merged->leaves[slot] = a;
+        M->leaf_dtype[slot] = a.dtype;
+      }
+      M->leaf_map[k][l] = slot;
+    }
+    for (int pc = 0; pc < pr->n_instr; ++pc) {
+      const uint32_t c = pr->ctrl[pc];
+      const bool has_imm = MD_VM_KIND(c) != MDHIP_VM_UNARY && MD_VM_KIND(c) != MDHIP_VM_WHERE &&
+                           (MD_VM_RS(c) == MDHIP_VM_SRC_CONST || (MD_VM_KIND(c) == MDHIP_VM_BINARY && MD_VM_LS(c) == MDHIP_VM_SRC_CONST));
+      M->imm_slot[k][pc] = 0;
+      if (has_imm) {
+        if (M->n_imm == MDHIP_VM_MAX_INSTR) return false;
+        merged->imm[M->n_imm] = pr->imm[pc];
+        M->imm_slot[k][pc] = M->n_imm++;
+      }
+    }
+  }
+  merged->n_leaves = M->n_leaves;
+  merged->n_instr = 1;  // a placeholder PUSH so that the merged table passes md_vm_build_iter
+  merged->ctrl[0] = MDHIP_VM_CTRL(MDHIP_VM_PUSH, 0, 0, 0, MDHIP_VM_SRC_LEAF, 0);
+  return M->n_leaves > 0;
+}
+
+static int eval_multi(const mdhip_vm_program *progs, const mdhip_array *outs, int n, bool *done) {
+  *done = false;
+  if (!jit::enabled()) return MDHIP_OK;
+  jit::Multi M;
+  mdhip_vm_program merged;
+  if (!merge_programs(progs, n, &M, &merged)) return MDHIP_OK;
+  for (int k = 0; k < n; ++k) {  // outputs: the compute dtype, contiguous, one shape
+    if (outs[k].dtype != merged.compute_dtype || outs[k].ndim != outs[0].ndim) return MDHIP_OK;
+    for (int d = 0; d < outs[0].ndim; ++d)
+      if (outs[k].shape[d] != outs[0].shape[d] || outs[k].strides[d] != outs[0].strides[d]) return MDHIP_OK;
+    if (((uintptr_t)outs[k].data & 15) != 0) return MDHIP_OK;
+  }
+  MdVmIter it;
+  if (md_vm_build_iter(&it, &merged, &outs[0], &outs[0]) != MDHIP_OK) return MDHIP_OK;
+  if (it.total < jit::min_elems()) return MDHIP_OK;
+  MdVmDev D;
+  to_dev(&merged, &D);
+  int64_t rows, inner;
+  if (!fast_geometry(it, merged.n_leaves, &merged, true, &D, &rows, &inner)) return MDHIP_OK;
+  int64_t bytes = (int64_t)n * it.total * (int64_t)md_dtype_size(merged.compute_dtype);
+  for (int l = 0; l < merged.n_leaves; ++l)
+    if (D.leaf[l].is) bytes += it.total * (int64_t)md_dtype_size(merged.leaves[l].dtype);
+  hipFunction_t fn = jit::get_multi(M, bytes > ((int64_t)320 << 20));
+  if (!fn) return MDHIP_OK;
+  jit::JArgs A;
+  memset(&A, 0, sizeof A);
+  for (int l = 0; l < merged.n_leaves; ++l) { A.leaf[l].p = D.leaf[l].p; A.leaf[l].os = D.leaf[l].os; A.leaf[l].is = D.leaf[l].is; }
+  for (int i = 0; i < M.n_imm; ++i) A.imm[i] = merged.imm[i];
+  for (int k = 0; k < n; ++k) A.outs[k] = outs[k].data;
+  A.rows = rows; A.inner = inner;
+  *done = true;
+  return jit::launch(fn, A, dim3((unsigned)md_grid_for(rows * (inner >> 2) + (rows == 1 ? 4 : 0))));
+}
+
 static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 template <class R, class T>
@@ -475,6 +555,32 @@ int mdhip_vm_eval(const mdhip_vm_program *pr, const mdhip_array *out) {
   if (out->dtype != pr->compute_dtype && out->dtype != MDHIP_BOOL)
     return md_fail(MDHIP_ETYPE, "vm_eval: out dtype must be the compute dtype or bool");
   return pr->compute_dtype == MDHIP_F32 ? eval_typed<float>(pr, out) : eval_typed<double>(pr, out);
+}
+
+int mdhip_vm_eval_multi(const mdhip_vm_program *progs, const mdhip_array *outs, int n) {
+  if (n < 1) return md_fail(MDHIP_EVALUE, "vm_eval_multi: no programs");
+  for (int k = 0; k < n; ++k) {
+    MD_TRY(md_vm_check(&progs[k]));
+    MD_TRY(md_check_array(&outs[k], "vm out"));
+  }
+  bool done = false;
+  MD_TRY(eval_multi(progs, outs, n, &done));
+  if (done) return MDHIP_OK;
+  for (int k = 0; k < n; ++k) MD_TRY(mdhip_vm_eval(&progs[k], &outs[k]));  // same results, one pass each
+  return MDHIP_OK;
+}
+
+int mdhip_vm_jit_probe_multi(const mdhip_vm_program *progs, int n, char *log, size_t log_cap) {
+  for (int k = 0; k < n; ++k) MD_TRY(md_vm_check(&progs[k]));
+  jit::Multi M;
+  mdhip_vm_program merged;
+  if (!merge_programs(progs, n, &M, &merged)) return md_fail(MDHIP_EVALUE, "jit probe: programs cannot share one launch");
+  std::vector<char> code;
+  std::string l;
+  const int rc = jit::compile(jit::gen_source_multi(M, false), &code, &l);
+  if (log && log_cap) { strncpy(log, l.c_str(), log_cap - 1); log[log_cap - 1] = 0; }
+  if (rc != 0) return md_fail(MDHIP_ERUNTIME, "fused-kernel compilation failed: %.300s", l.c_str());
+  return MDHIP_OK;
 }
 
 int mdhip_vm_jit_probe(const mdhip_vm_program *pr, int kind, int reduce_op, int out_is_bool, char *log, size_t log_cap) {

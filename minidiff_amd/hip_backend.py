@@ -225,6 +225,7 @@ class HipBackendTable:
     # ---- extras the harness uses (not part of the reference table) -----------
     _synchronize = staticmethod(nd.synchronize)
     _materialize = staticmethod(nd.materialize)
+    _materialize_many = staticmethod(nd.materialize_many)
 
 
 def public_names() -> list:

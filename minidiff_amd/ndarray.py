@@ -48,7 +48,7 @@ def lazy_enabled() -> bool:
 
 
 # launches issued for pending expressions (tests assert that fusion really happened)
-FUSION_STATS = {"vm_eval": 0, "vm_reduce": 0}
+FUSION_STATS = {"vm_eval": 0, "vm_reduce": 0, "vm_eval_multi": 0}
 
 _DTYPE_CODES = {
     np.dtype(np.bool_): _capi.BOOL,
@@ -1953,6 +1953,50 @@ def materialize(a):
     if isinstance(a, DeviceArray) and a._buf is None:
         a._materialize()
     return a
+
+
+def materialize_many(arrays):
+    """Evaluate several pending arrays, sharing one pass among those of equal shape and float
+    type (gradients of one backward sweep read the same operands: each distinct leaf is then
+    loaded once and all results are stored by the same kernel, `mdhip_vm_eval_multi`)."""
+    pending, seen = [], set()
+    for a in arrays:
+        if isinstance(a, DeviceArray) and a._expr is not None and id(a) not in seen:
+            seen.add(id(a))
+            pending.append(a)
+    groups = {}
+    for a in pending:
+        if a.size and a.dtype in _FLOAT_DT and _FLOAT_DT[a.dtype] == a._expr.cdt:
+            groups.setdefault((a.shape, a._expr.cdt), []).append(a)
+    for group in groups.values():
+        while len(group) >= 2:
+            batch, leaves = [], {}
+            for a in group:
+                merged = dict(leaves)
+                merged.update(a._expr.leaves)
+                if len(batch) < 4 and len(merged) <= _lz.MAX_LEAVES:
+                    batch.append(a)
+                    leaves = merged
+            taken = {id(b) for b in batch}
+            group = [a for a in group if id(a) not in taken]
+            if len(batch) < 2:
+                continue
+            progs = (_capi.VmProgram * len(batch))()
+            outs = (_capi.ArrayDesc * len(batch))()
+            keep = []
+            for k, a in enumerate(batch):
+                prog, kp = _lz.build_program(a._expr, a.shape)
+                progs[k] = prog
+                keep.append(kp)
+                a._buf = _Buffer(_prod(a.shape) * a.dtype.itemsize)
+                a._expr = None
+                outs[k] = a.desc()
+            _lib().vm_eval_multi(progs, outs, len(batch))
+            FUSION_STATS["vm_eval_multi"] += 1
+            del keep
+    for a in pending:
+        a.materialize()
+    return arrays
 
 
 def synchronize():

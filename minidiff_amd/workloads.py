@@ -15,11 +15,9 @@ import numpy as np
 def _finish(md, *tensors):
     """A sweep is complete when its gradients are IN MEMORY: in lazy mode this is
     what triggers the fused kernels (a no-op for eager engines)."""
-    mat = getattr(md.backend, "_materialize", None)
+    mat = getattr(md.backend, "_materialize_many", None)
     if mat is not None:
-        for t in tensors:
-            if t is not None and t.grad is not None:
-                mat(t.grad._data)
+        mat([t.grad._data for t in tensors if t is not None and t.grad is not None])
 
 
 def _randn(seed, shape, scale=1.0):

@@ -372,6 +372,14 @@ int mdhip_vm_jit_probe(const mdhip_vm_program *, int, int, int, char *, size_t) 
   return md_fail(MDHIP_ERUNTIME, "the CPU test double has no run-time compiler");
 }
 int mdhip_vm_jit_stats(int64_t stats[2]) { stats[0] = stats[1] = 0; return MDHIP_OK; }
+int mdhip_vm_eval_multi(const mdhip_vm_program *progs, const mdhip_array *outs, int n) {
+  if (n < 1) return md_fail(MDHIP_EVALUE, "vm_eval_multi: no programs");
+  for (int k = 0; k < n; ++k) MD_TRY(mdhip_vm_eval(&progs[k], &outs[k]));
+  return MDHIP_OK;
+}
+int mdhip_vm_jit_probe_multi(const mdhip_vm_program *, int, char *, size_t) {
+  return md_fail(MDHIP_ERUNTIME, "the CPU test double has no run-time compiler");
+}
 
 // data-parallel entry points: the double has no collective; world size 1 only.
 int mdhip_comm_get_unique_id(uint8_t uid[MDHIP_UID_BYTES]) { memset(uid, 0, MDHIP_UID_BYTES); return MDHIP_OK; }

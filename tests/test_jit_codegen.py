@@ -69,3 +69,33 @@ def test_generated_kernels_compile(lib, on_gpu, product):
                 plib.vm_jit_probe(prog, 2, rop, 0, log, len(log))
                 n += 2
     assert n > 90
+
+
+def test_generated_multi_output_kernel_compiles(lib, on_gpu, product):
+    """The multi-output form (mdhip_vm_eval_multi): merged leaf table, one inlined body per
+    program, shared immediates array."""
+    from minidiff_amd import lazy as lz, ndarray as nd
+    plib, log = product
+    prev = nd.set_lazy(True)
+    try:
+        rng = np.random.default_rng(1)
+        x = nd.asarray(rng.standard_normal((8, 16)).astype(np.float32))
+        y = nd.asarray(rng.standard_normal((8, 16)).astype(np.float32))
+        b = nd.asarray(rng.standard_normal((16,)).astype(np.float32))
+        s = nd.multiply(nd.sin(x), y)
+        arrs = [nd.multiply(nd.multiply(s, 2.0), nd.cos(x)), nd.add(nd.multiply(s, nd.sin(x)), b),
+                nd.where(nd.greater(y, 0.25), nd.exp(x), -1.5), nd.subtract(2.0, x)]
+        for n in (2, 3, 4):
+            progs = (_capi.VmProgram * n)()
+            keep = []
+            for k in range(n):
+                prog, kp = lz.build_program(arrs[k]._expr, arrs[k].shape)
+                progs[k] = prog
+                keep.append(kp)
+            plib.vm_jit_probe_multi(progs, n, log, len(log))
+        one = (_capi.VmProgram * 1)()
+        one[0] = lz.build_program(arrs[0]._expr, arrs[0].shape)[0]
+        with pytest.raises(ValueError):
+            plib.vm_jit_probe_multi(one, 1, log, len(log))
+    finally:
+        nd.set_lazy(prev)

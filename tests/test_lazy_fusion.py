@@ -128,7 +128,8 @@ def _sweeps(nd, on_gpu, want_gpu):
     s_l, step_l = workloads.make_cfg3(md, n=4096)
     out = step_l()
     assert nd.FUSION_STATS["vm_reduce"] - before["vm_reduce"] == 1      # sum((sin(x)*y)**2) in one pass
-    assert nd.FUSION_STATS["vm_eval"] - before["vm_eval"] == 2          # x.grad and y.grad, one pass each
+    assert nd.FUSION_STATS["vm_eval_multi"] - before["vm_eval_multi"] == 1  # x.grad and y.grad share one call
+    assert nd.FUSION_STATS["vm_eval"] - before["vm_eval"] == 0
     _close(s_l["x"].grad.as_numpy(), gx_e, 1e-6)
     _close(s_l["y"].grad.as_numpy(), gy_e, 1e-6)
     before = dict(nd.FUSION_STATS)
@@ -137,6 +138,46 @@ def _sweeps(nd, on_gpu, want_gpu):
     assert nd.FUSION_STATS["vm_reduce"] - before["vm_reduce"] == 2      # loss sum + fused bias-gradient column sum
     _close(c_l["W"].grad.as_numpy(), gw_e, 1e-6)
     _close(c_l["b"].grad.as_numpy(), gb_e, 1e-6)
+
+
+def _multi(nd, on_gpu, want_gpu):
+    """materialize_many: pending results of one shape evaluated together equal their separate
+    evaluation (on the device above the compiled-path threshold: ONE kernel, leaves read once)."""
+    if want_gpu != on_gpu:
+        pytest.skip("other twin")
+    rng = np.random.default_rng(5)
+    for n, dt in ((1 << 19, np.float32), (1000, np.float32), (300_001, np.float64)):
+        xh = rng.standard_normal(n).astype(dt)
+        yh = rng.standard_normal(n).astype(dt)
+        zh = rng.standard_normal((1,)).astype(dt)
+        x, y, z = nd.asarray(xh), nd.asarray(yh), nd.asarray(zh)
+        s = nd.multiply(nd.sin(x), y)
+        outs = [nd.multiply(nd.multiply(s, 2.0), nd.cos(x)),                 # shares sin(x)*y and the leaves
+                nd.add(nd.multiply(s, nd.sin(x)), z),                        # + a broadcast one-element leaf
+                nd.where(nd.greater(y, 0.25), nd.exp(x), -1.5),              # constants in every program
+                nd.subtract(x, y),
+                nd.power(nd.absolute(y), 0.5)]                               # a 5th: left for a single pass
+        other_shape = nd.multiply(nd.asarray(xh[:10]), 3.0)
+        boolean = nd.greater(x, y)                                           # not a float result: evaluated on its own
+        exp = [2.0 * (np.sin(xh) * yh) * np.cos(xh), (np.sin(xh) * yh) * np.sin(xh) + zh,
+               np.where(yh > 0.25, np.exp(xh), dt(-1.5)), xh - yh, np.abs(yh) ** dt(0.5)]
+        before = dict(nd.FUSION_STATS)
+        nd.materialize_many(outs + [other_shape, boolean, outs[0], x])
+        assert nd.FUSION_STATS["vm_eval_multi"] - before["vm_eval_multi"] == 1   # four results in one call
+        assert nd.FUSION_STATS["vm_eval"] - before["vm_eval"] == 3               # the fifth, the other shape, the bool
+        for o in outs + [other_shape, boolean]:
+            assert o._expr is None
+        tol = 2e-6 if dt is np.float32 else 1e-14
+        for o, e in zip(outs, exp):
+            assert o.dtype == dt
+            _close(np.asarray(o), e.astype(dt), tol)
+        assert np.array_equal(np.asarray(boolean), xh > yh)
+        _close(np.asarray(other_shape), xh[:10] * dt(3.0), tol)
+
+
+def test_multi_cpu(lazy_nd, on_gpu): _multi(lazy_nd, on_gpu, False)
+@gpu
+def test_multi_gpu(lazy_nd, on_gpu): _multi(lazy_nd, on_gpu, True)
 
 
 def test_sweeps_cpu(lazy_nd, on_gpu): _sweeps(lazy_nd, on_gpu, False)
