@@ -210,12 +210,23 @@ def main():
     comm_kind = "none"
     if use_dist and args.workload in ("cfg2", "cfg4"):
         if args.comm == "rccl":
+            err = None
             try:
                 comm = dp.RcclComm(rank, world, dist)
+            except Exception as e:  # communicator could not be built on this rank
+                err = e
+            # every rank must take the same path: agree over the gloo control plane
+            flags = [None] * world
+            dist.all_gather_object(flags, err is None)
+            if all(flags):
                 comm_kind = "rccl-direct"
-            except Exception as e:  # communicator could not be built: same data path via torch's RCCL
-                print(f"[rank {rank}] direct RCCL communicator failed ({e}); using torch.distributed nccl", file=sys.stderr)
-        if comm is None:
+            else:
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                print(f"[rank {rank}] direct RCCL communicator unavailable ({err or 'failed on another rank'}); "
+                      "using torch.distributed nccl", file=sys.stderr)
+        if comm is None:  # same data path through torch's RCCL
             comm = dp.TorchComm(rank, world, dist, torch)
             comm_kind = "rccl-torch"
     sync = dp.GradSync(md, state["params"] if args.workload == "cfg4" else state["params"][:1], comm, force=force_dist,
@@ -268,6 +279,29 @@ def main():
 
     kernel_ms = timer.collect()
     ms_per_step = elapsed / args.steps * 1e3
+
+    # the collective alone (un-overlapped, outside the timed region): time and bus bandwidth
+    allreduce_ms = busbw = None
+    if comm is not None and sync.active:
+        import ctypes as C
+        grads = [p.grad for p in sync.params]
+        buf = sync.bucket if sync.bucket is not None else grads[0]._data
+        e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+        lib.event_create(C.byref(e0)); lib.event_create(C.byref(e1))
+        reps = 5
+        comm.allreduce_sum_(buf)
+        barrier()
+        lib.event_record(e0)
+        for _ in range(reps):
+            comm.allreduce_sum_(buf)
+        lib.event_record(e1)
+        lib.sync()
+        if comm_kind == "rccl-direct":
+            lib.event_elapsed_ms(e0, e1, C.byref(ms))
+            allreduce_ms = float(ms.value) / reps
+        if allreduce_ms and world > 1:
+            busbw = 2.0 * (world - 1) / world * sync.nbytes / (allreduce_ms * 1e-3) / 1e9
+        barrier()
     # cfg2/cfg3/cfg5: every rank runs a full sweep on its own shard (weak); cfg4: one global batch (strong)
     if args.workload == "cfg4":
         value = args.steps / elapsed
@@ -341,7 +375,8 @@ def main():
                 "cfg4": f"cfg4: sum(relu(X@W+b)).backward(), global batch {n} x 4096 -> 4096, row-sharded",
                 "cfg5": f"cfg5: second order on {n}x{n} matmul, 5 GEMMs"}[args.workload],
                 "parallelism": f"dp{world}", "graph_replay": bool(args.graph), "collective": comm_kind, "allreduce_bytes": sync.nbytes if use_dist else 0,
-                "allreduce_overlapped_sweeps": sync.overlapped},
+                "allreduce_overlapped_sweeps": sync.overlapped,
+                "allreduce_alone_ms": allreduce_ms, "allreduce_busbw_GBps": busbw},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
