@@ -147,7 +147,7 @@ def normalize_axes(axis, ndim) -> tuple:
 
 
 class DeviceArray:
-    __slots__ = ("_buf", "_offset", "shape", "_strides", "dtype", "_code", "_expr", "__weakref__")
+    __slots__ = ("_buf", "_offset", "shape", "_strides", "dtype", "_code", "_expr", "_cdesc", "__weakref__")
     __array_priority__ = 1000.0
     __hash__ = None
 
@@ -159,6 +159,7 @@ class DeviceArray:
         self.dtype = dtype
         self._code = code if code >= 0 else dtype_code(dtype)
         self._expr = None  # pending expression (lazy mode); _buf is None until materialised
+        self._cdesc = None  # own-shape C descriptor, built once (geometry and block never change)
 
     # ---- lazy evaluation -----------------------------------------------------
     @staticmethod
@@ -204,6 +205,15 @@ class DeviceArray:
         code = dtype_code(dtype)
         buf = _Buffer(_prod(shape) * dtype.itemsize)
         return DeviceArray(buf, 0, shape, _c_strides(shape), dtype, code)
+
+    @staticmethod
+    def _new(shape: tuple, dtype: np.dtype) -> "DeviceArray":
+        """Result buffer of an op: `shape` is already a validated tuple of ints, `dtype` an np.dtype
+        (skips the argument normalisation of `empty`; the dispatch cost of a small op is Python)."""
+        n = dtype.itemsize
+        for s in shape:
+            n *= s
+        return DeviceArray(_Buffer(n), 0, shape, _c_strides(shape), dtype, dtype_code(dtype))
 
     @staticmethod
     def from_numpy(arr) -> "DeviceArray":
@@ -276,29 +286,35 @@ class DeviceArray:
 
     def desc(self, shape=None) -> ArrayDesc:
         """C descriptor; with `shape`, broadcast (stride 0) to that shape."""
+        if shape is None or shape == self.shape:
+            d = self._cdesc
+            if d is None:
+                d = ArrayDesc()
+                d.data = self.ptr
+                d.dtype = self._code
+                nd = len(self.shape)
+                d.ndim = nd
+                if nd:
+                    d.shape[:nd] = self.shape
+                    d.strides[:nd] = self._strides
+                self._cdesc = d
+            return d
         d = ArrayDesc()
         d.data = self.ptr
         d.dtype = self._code
-        if shape is None or shape == self.shape:
-            nd = len(self.shape)
-            d.ndim = nd
-            if nd:
-                d.shape[:nd] = self.shape
-                d.strides[:nd] = self._strides
-        else:
-            nd = len(shape)
-            lead = nd - len(self.shape)
-            st = [0] * nd
-            for i, (n, s) in enumerate(zip(self.shape, self._strides)):
-                tgt = shape[lead + i]
-                if n == tgt:
-                    st[lead + i] = s
-                elif n != 1:
-                    raise ValueError(f"operands could not be broadcast together with shapes {self.shape} {shape}")
-            d.ndim = nd
-            if nd:
-                d.shape[:nd] = shape
-                d.strides[:nd] = st
+        nd = len(shape)
+        lead = nd - len(self.shape)
+        st = [0] * nd
+        for i, (n, s) in enumerate(zip(self.shape, self._strides)):
+            tgt = shape[lead + i]
+            if n == tgt:
+                st[lead + i] = s
+            elif n != 1:
+                raise ValueError(f"operands could not be broadcast together with shapes {self.shape} {shape}")
+        d.ndim = nd
+        if nd:
+            d.shape[:nd] = shape
+            d.strides[:nd] = st
         return d
 
     # ---- host transfer ------------------------------------------------------
@@ -705,7 +721,7 @@ def _binary(ufunc, code, a, b, out=None):
     da = _operand_desc(a, shape, 0 if a_arr else _scalar_code(a, cdt))
     db = _operand_desc(b, shape, 0 if b_arr else _scalar_code(b, cdt))
     if out is None:
-        res = DeviceArray.empty(shape, odt)
+        res = DeviceArray._new(shape, odt)
         _lib().binary(code, da, db, res.desc(), _DTYPE_CODES[cdt])
         return res
     _before_write(out)
@@ -717,7 +733,7 @@ def _binary(ufunc, code, a, b, out=None):
     if odt == out.dtype:
         _lib().binary(code, da, db, out.desc(), _DTYPE_CODES[cdt])
     else:
-        tmp = DeviceArray.empty(shape, odt)
+        tmp = DeviceArray._new(shape, odt)
         _lib().binary(code, da, db, tmp.desc(), _DTYPE_CODES[cdt])
         _copy_into(out, tmp)
     return out
@@ -748,7 +764,7 @@ def _unary(ufunc, code, x):
             res = _lazy_node(_lz.UNARY, code, (x,), pcdt, x.shape, loop[1])
             if res is not None:
                 return res
-    res = DeviceArray.empty(x.shape, loop[1])
+    res = DeviceArray._new(x.shape, loop[1])
     _lib().unary(code, x.desc(), res.desc())
     return res
 
@@ -864,7 +880,7 @@ def where(condition, x=None, y=None):
             res = _lazy_node(_lz.WHERE, 0, (c, a, b), pcdt, shape, odt)
             if res is not None:
                 return res
-    res = DeviceArray.empty(shape, odt)
+    res = DeviceArray._new(shape, odt)
     dc = _operand_desc(c, shape, _capi.I64)
     da = _operand_desc(a, shape, 0 if isinstance(a, DeviceArray) else _scalar_code(a, odt))
     db = _operand_desc(b, shape, 0 if isinstance(b, DeviceArray) else _scalar_code(b, odt))
