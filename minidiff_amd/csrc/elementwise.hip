@@ -207,6 +207,55 @@ __global__ void __launch_bounds__(MD_BLOCK) k_where_fast(FastOp<Tcnd> c, FastOp<
   }
 }
 
+// ------------------------------------------------------------- transposed x ----
+// out[b][r][c] = F(x[b*xb + c*xc + r]) : the operand is contiguous along the axis that is
+// NOT out's contiguous one (x.T, swapaxes, transpose_grad: definitions.py:144-152,416-420).
+// 64x64 tile through LDS: loads run along r (x's unit stride), stores along c (out's).
+template <class F, class Tc, class To>
+__global__ void __launch_bounds__(MD_BLOCK) k_unary_tr(const void *x, int xdt, int64_t xb, int64_t xc, To *out, int64_t R, int64_t Cn,
+                                                      int tiles_r, int tiles_c) {
+  __shared__ Tc tile[64][65];
+  int64_t bid = blockIdx.x;
+  const int64_t per = (int64_t)tiles_r * tiles_c;
+  const int64_t b = bid / per;
+  bid -= b * per;
+  const int tr = (int)(bid / tiles_c), tc = (int)(bid - (int64_t)tr * tiles_c);
+  const int64_t r0 = (int64_t)tr * 64, c0 = (int64_t)tc * 64;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int c = w + 4 * k;
+    if (r0 + l < R && c0 + c < Cn) tile[c][l] = md_load<Tc>(x, xdt, b * xb + (c0 + c) * xc + r0 + l);
+  }
+  __syncthreads();
+  To *o = out + b * R * Cn;
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int r = w + 4 * k;
+    if (r0 + r < R && c0 + l < Cn) o[(r0 + r) * Cn + c0 + l] = md_to_out<To>(F::apply(tile[l][r]));
+  }
+}
+// eligibility: out C-contiguous over (B, R, C) after the iterator's collapse, x unit-stride along R
+static bool tr_geom(const MdIter &it, int xk, int ok, int64_t *B, int64_t *R, int64_t *Cn, int64_t *xb, int64_t *xc) {
+  if (it.ndim != 2 && it.ndim != 3) return false;
+  const int d0 = it.ndim - 2, d1 = it.ndim - 1;
+  *R = it.shape[d0];
+  *Cn = it.shape[d1];
+  if (*R < 32 || *Cn < 32) return false;
+  if (it.strides[ok][d1] != 1 || it.strides[ok][d0] != *Cn) return false;
+  if (it.strides[xk][d0] != 1 || it.strides[xk][d1] < *R) return false;
+  *xc = it.strides[xk][d1];
+  *B = 1;
+  *xb = 0;
+  if (it.ndim == 3) {
+    *B = it.shape[0];
+    if (it.strides[ok][0] != *R * *Cn || it.strides[xk][0] < 0) return false;
+    *xb = it.strides[xk][0];
+  }
+  const int64_t blocks = *B * ((*R + 63) / 64) * ((*Cn + 63) / 64);
+  return blocks < (1ll << 31);
+}
+
 // ------------------------------------------------------- fast-path eligibility ----
 struct FastGeom {
   int64_t rows, inner;
@@ -275,6 +324,12 @@ struct HipExec {
       if (nt_for(bytes)) k_unary_fast<F, Tc, To, Tx, true><<<md_grid_for(work), MD_BLOCK, 0, st>>>(fx, sx, (To *)out->data, g.rows, g.inner);
       else k_unary_fast<F, Tc, To, Tx, false><<<md_grid_for(work), MD_BLOCK, 0, st>>>(fx, sx, (To *)out->data, g.rows, g.inner);
       return MD_LAUNCH_CHECK("unary(fast)");
+    }
+    int64_t B, R, Cn, xb, xc;
+    if (!x->is_scalar && it.total >= (1 << 14) && tr_geom(it, 0, 1, &B, &R, &Cn, &xb, &xc)) {
+      const int tr = (int)((R + 63) / 64), tc = (int)((Cn + 63) / 64);
+      k_unary_tr<F, Tc, To><<<(unsigned)(B * tr * tc), MD_BLOCK, 0, st>>>(x->data, x->dtype, xb, xc, (To *)out->data, R, Cn, tr, tc);
+      return MD_LAUNCH_CHECK("unary(transposed)");
     }
     k_unary_generic<F, Tc, To><<<md_grid_for(it.total), MD_BLOCK, 0, st>>>(it, x->data, x->dtype, x->is_scalar, sx, (To *)out->data);
     return MD_LAUNCH_CHECK("unary(generic)");

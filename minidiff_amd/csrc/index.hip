@@ -33,6 +33,23 @@ __global__ void __launch_bounds__(MD_BLOCK) k_gather(mdhip_index_plan pl, int64_
   }
 }
 
+// Contiguous runs (a[idx] selecting whole rows, take along an outer axis): when the last plan
+// axis is contiguous on both sides and no index array varies along it, 16-B units move instead
+// of elements; `vshift` = log2(elements per unit).
+__global__ void __launch_bounds__(MD_BLOCK) k_gather_vec(mdhip_index_plan pl, int64_t total_v, int vshift, const uint4 *__restrict__ src,
+                                                        uint4 *__restrict__ out, MdIter oit, int *err) {
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_v; i += gs) {
+    int64_t pos[MDHIP_MAX_NDIM];
+    bool oob = false;
+    const int64_t off = md_plan_offset(pl, i << vshift, pos, &oob);
+    if (oob) { *err = 1; continue; }
+    int64_t oo = 0;
+    for (int d = 0; d < pl.ndim; ++d) oo += pos[d] * oit.strides[0][d];
+    out[oo >> vshift] = src[off >> vshift];
+  }
+}
+
 __global__ void __launch_bounds__(MD_BLOCK) k_check_bounds(mdhip_index_plan pl, int64_t total, int *err) {
   const int64_t gs = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
@@ -308,6 +325,21 @@ int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const m
   hipStream_t st = md_stream();
   (void)hipMemsetAsync(flag, 0, sizeof(int), st);
   const int grid = md_grid_for(total);
+  // whole 16-B units when the innermost axis is a contiguous run on both sides
+  const int es = (int)md_dtype_size(dtype);
+  const int nd = pl->ndim;
+  bool runs = nd >= 1 && (es == 1 || es == 4 || es == 8) && total >= 4096;
+  const int V = runs ? 16 / es : 1;
+  if (runs) {
+    runs = pl->src_strides[nd - 1] == 1 && out->strides[nd - 1] == 1 && (pl->shape[nd - 1] % V) == 0 &&
+           ((uintptr_t)src & 15) == 0 && ((uintptr_t)out->data & 15) == 0;
+    for (int k = 0; runs && k < pl->n_idx; ++k) runs = pl->idx_strides[k][nd - 1] == 0 && (pl->idx_mult[k] % V) == 0;
+    for (int d = 0; runs && d < nd - 1; ++d) runs = (pl->src_strides[d] % V) == 0 && (out->strides[d] % V) == 0;
+  }
+  if (runs) {
+    const int vshift = V == 16 ? 4 : V == 4 ? 2 : 1;
+    k_gather_vec<<<md_grid_for(total / V), MD_BLOCK, 0, st>>>(*pl, total / V, vshift, (const uint4 *)src, (uint4 *)out->data, oit, (int *)flag);
+  } else
   switch (md_dtype_size(dtype)) {
     case 1: k_gather<uint8_t><<<grid, MD_BLOCK, 0, st>>>(*pl, total, (const uint8_t *)src, (uint8_t *)out->data, oit, (int *)flag); break;
     case 4: k_gather<uint32_t><<<grid, MD_BLOCK, 0, st>>>(*pl, total, (const uint32_t *)src, (uint32_t *)out->data, oit, (int *)flag); break;

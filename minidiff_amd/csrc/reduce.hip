@@ -282,6 +282,148 @@ __global__ void __launch_bounds__(MD_BLOCK) k_arg_block(MdRedPlan pl, const void
   }
 }
 
+// Contiguous reduced axis (argmax over the last axis): one block per output, 16-B loads, two in
+// flight per lane. A lane meets its indices in increasing order, so "strictly better" keeps the
+// first of equal values (and the first NaN), as np.argmax does; lanes are merged with RArg::combine.
+template <bool IsMax, class T, bool FINAL>
+__global__ void __launch_bounds__(MD_BLOCK) k_arg_rows_vec(MdRedPlan pl, const T *__restrict__ x, int64_t splits, int64_t chunk,
+                                                          T *__restrict__ pval, int64_t *__restrict__ pidx) {
+  constexpr int V = 16 / sizeof(T);
+  __shared__ T sv[MD_BLOCK / 64];
+  __shared__ int64_t si[MD_BLOCK / 64];
+  const int64_t b = blockIdx.x;
+  const int64_t o = b / splits, s = b - o * splits;
+  int64_t xo, oo;
+  md_red_kept_offsets(pl, o, &xo, &oo);
+  // this block's slice [lo, hi) of the row (long rows are cut into `splits` slices)
+  const int64_t lo = s * chunk;
+  int64_t hi = lo + chunk;
+  if (hi > pl.n_red) hi = pl.n_red;
+  const T *p = x + xo + lo;
+  const int64_t n = hi - lo;
+  md_argpair<T> acc = RArg<IsMax>::template identity<T>();
+  // (written as selects: the branchy form `if (first || better) { v = ..; i = ..; }` was observed to
+  // lose the update on gfx950 with this compiler)
+  auto take = [&](T v, int64_t r) {
+    const bool up = (acc.i == INT64_MAX) | RArg<IsMax>::better(v, acc.v);
+    acc.v = up ? v : acc.v;
+    acc.i = up ? r : acc.i;
+  };
+  int64_t head = (V - (int64_t)(((uintptr_t)p / sizeof(T)) % V)) % V;
+  if (head > n) head = n;
+  if ((int64_t)threadIdx.x < head) take(p[threadIdx.x], lo + threadIdx.x);
+  const int64_t nvec = (n - head) / V;
+  const MdVec<T, V> *pv = reinterpret_cast<const MdVec<T, V> *>(p + head);
+  int64_t i = threadIdx.x;
+  for (; i + blockDim.x < nvec; i += 2 * blockDim.x) {
+    const MdVec<T, V> t = pv[i], u = pv[i + blockDim.x];
+#pragma unroll
+    for (int j = 0; j < V; ++j) take(t.v[j], lo + head + i * V + j);
+#pragma unroll
+    for (int j = 0; j < V; ++j) take(u.v[j], lo + head + (i + blockDim.x) * V + j);
+  }
+  if (i < nvec) {
+    const MdVec<T, V> t = pv[i];
+#pragma unroll
+    for (int j = 0; j < V; ++j) take(t.v[j], lo + head + i * V + j);
+  }
+  const int64_t t0 = head + nvec * V;
+  if (t0 + threadIdx.x < n) take(p[t0 + threadIdx.x], lo + t0 + threadIdx.x);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    md_argpair<T> other{md_shfl_down(acc.v, d), md_shfl_down(acc.i, d)};
+    acc = RArg<IsMax>::combine(acc, other);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) { sv[w] = acc.v; si[w] = acc.i; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < nw; ++k) acc = RArg<IsMax>::combine(acc, md_argpair<T>{sv[k], si[k]});
+    if constexpr (FINAL) pidx[oo] = acc.i;
+    else { pval[b] = acc.v; pidx[b] = acc.i; }
+  }
+}
+template <bool IsMax, class T>
+__global__ void __launch_bounds__(MD_BLOCK) k_arg_rows_finish(MdRedPlan pl, const T *pval, const int64_t *pidx, int64_t splits, int64_t *out) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= pl.n_out) return;
+  md_argpair<T> a = RArg<IsMax>::template identity<T>();
+  for (int64_t s = 0; s < splits; ++s) a = RArg<IsMax>::combine(a, md_argpair<T>{pval[o * splits + s], pidx[o * splits + s]});
+  int64_t xo, oo;
+  md_red_kept_offsets(pl, o, &xo, &oo);
+  out[oo] = a.i;
+}
+
+// Contiguous KEPT axis (argmax over axis 0 of a row-major matrix): a lane owns V adjacent
+// columns and walks the rows (coalesced 16-B loads, four rows in flight); the four waves of a
+// block take rows r, r+1, r+2, r+3 (mod 4) and are merged through LDS; row chunks (gridDim.y)
+// leave (value, index) partials merged by k_arg_cols_finish.
+template <bool IsMax, class T, bool FINAL>
+__global__ void __launch_bounds__(MD_BLOCK) k_arg_cols_vec(const T *__restrict__ x, int64_t n_out, int64_t n_red, int64_t rs,
+                                                          int64_t chunk, T *__restrict__ pval, int64_t *__restrict__ pidx) {
+  constexpr int V = 16 / sizeof(T);
+  __shared__ T sv[3][64][V];
+  __shared__ int64_t si[3][64][V];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t col = ((int64_t)blockIdx.x * 64 + cx) * V;
+  const int64_t s = blockIdx.y, r0 = s * chunk;
+  int64_t r1 = r0 + chunk;
+  if (r1 > n_red) r1 = n_red;
+  T bv[V];
+  int64_t bi[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { bv[j] = T(); bi[j] = INT64_MAX; }
+  if (col < n_out) {
+    const T *p = x + col;
+    int64_t r = r0 + ry;
+    for (; r + 12 < r1; r += 16) {
+      MdVec<T, V> t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const MdVec<T, V> *>(p + (r + 4 * u) * rs);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const bool up = (bi[j] == INT64_MAX) | RArg<IsMax>::better(t[u].v[j], bv[j]);
+          bv[j] = up ? t[u].v[j] : bv[j];
+          bi[j] = up ? r + 4 * u : bi[j];
+        }
+    }
+    for (; r < r1; r += 4) {
+      const MdVec<T, V> t = *reinterpret_cast<const MdVec<T, V> *>(p + r * rs);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const bool up = (bi[j] == INT64_MAX) | RArg<IsMax>::better(t.v[j], bv[j]);
+        bv[j] = up ? t.v[j] : bv[j];
+        bi[j] = up ? r : bi[j];
+      }
+    }
+  }
+  if (ry > 0) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sv[ry - 1][cx][j] = bv[j]; si[ry - 1][cx][j] = bi[j]; }
+  }
+  __syncthreads();
+  if (ry == 0 && col < n_out) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      md_argpair<T> a{bv[j], bi[j]};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) a = RArg<IsMax>::combine(a, md_argpair<T>{sv[k][cx][j], si[k][cx][j]});
+      if constexpr (FINAL) pidx[col + j] = a.i;
+      else { pval[s * n_out + col + j] = a.v; pidx[s * n_out + col + j] = a.i; }
+    }
+  }
+}
+template <bool IsMax, class T>
+__global__ void __launch_bounds__(MD_BLOCK) k_arg_cols_finish(const T *pval, const int64_t *pidx, int64_t n_out, int64_t splits, int64_t *out) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_out) return;
+  md_argpair<T> a = RArg<IsMax>::template identity<T>();
+  for (int64_t s = 0; s < splits; ++s) a = RArg<IsMax>::combine(a, md_argpair<T>{pval[s * n_out + o], pidx[s * n_out + o]});
+  out[o] = a.i;
+}
+
 static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 struct HipExec {
@@ -368,6 +510,61 @@ struct HipExec {
   template <bool IsMax, class T>
   static int argreduce(const MdRedPlan &pl, const mdhip_array *x, const mdhip_array *out) {
     hipStream_t st = md_stream();
+    if constexpr (sizeof(T) >= 4) {
+      constexpr int V = 16 / sizeof(T);
+      const bool same = x->dtype == md_dtype_of<T>::value;
+      // kept axis contiguous (argmax over the rows of a row-major matrix)
+      if (same && pl.nk == 1 && pl.nr == 1 && pl.kx[0] == 1 && pl.ko[0] == 1 && pl.n_out >= 256 && (pl.n_out % V) == 0 &&
+          (pl.rx[0] % V) == 0 && ((uintptr_t)x->data & 15) == 0 && pl.n_red >= 16) {
+        const int64_t n_out = pl.n_out, n_red = pl.n_red;
+        const int64_t bxv = ceil_div(n_out, 64 * V);
+        int64_t splits = 1024 / bxv;
+        if (splits > n_red / 64) splits = n_red / 64;
+        if (splits > 65535) splits = 65535;
+        if (splits < 1) splits = 1;
+        const int64_t chunk = ceil_div(ceil_div(n_red, splits), 16) * 16;
+        splits = ceil_div(n_red, chunk);
+        const T *xp = (const T *)x->data;
+        if (splits == 1) {
+          k_arg_cols_vec<IsMax, T, true><<<dim3((unsigned)bxv, 1), MD_BLOCK, 0, st>>>(xp, n_out, n_red, pl.rx[0], chunk, nullptr, (int64_t *)out->data);
+          return MD_LAUNCH_CHECK("argreduce(cols,vec)");
+        }
+        void *pv = nullptr, *pi = nullptr;
+        MD_TRY(mdhip_alloc((size_t)(splits * n_out) * sizeof(T), &pv));
+        int rc = mdhip_alloc((size_t)(splits * n_out) * sizeof(int64_t), &pi);
+        if (rc != MDHIP_OK) { mdhip_free(pv); return rc; }
+        k_arg_cols_vec<IsMax, T, false><<<dim3((unsigned)bxv, (unsigned)splits), MD_BLOCK, 0, st>>>(xp, n_out, n_red, pl.rx[0], chunk, (T *)pv, (int64_t *)pi);
+        k_arg_cols_finish<IsMax, T><<<(unsigned)ceil_div(n_out, MD_BLOCK), MD_BLOCK, 0, st>>>((const T *)pv, (const int64_t *)pi, n_out, splits, (int64_t *)out->data);
+        rc = MD_LAUNCH_CHECK("argreduce(cols,vec,split)");
+        mdhip_free(pv);
+        mdhip_free(pi);
+        return rc;
+      }
+      // reduced axis contiguous
+      if (same && pl.nr == 1 && pl.rx[0] == 1 && pl.n_red >= 1024 && pl.n_out < (1ll << 30)) {
+        // ~2048 blocks in total, each with >= 8192 items of its row
+        int64_t splits = 2048 / pl.n_out;
+        const int64_t max_splits = ceil_div(pl.n_red, 8192);
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        const int64_t chunk = ceil_div(ceil_div(pl.n_red, splits), V) * V;
+        splits = ceil_div(pl.n_red, chunk);
+        if (splits == 1) {
+          k_arg_rows_vec<IsMax, T, true><<<(unsigned)pl.n_out, MD_BLOCK, 0, st>>>(pl, (const T *)x->data, 1, chunk, nullptr, (int64_t *)out->data);
+          return MD_LAUNCH_CHECK("argreduce(rows,vec)");
+        }
+        void *pv = nullptr, *pi = nullptr;
+        MD_TRY(mdhip_alloc((size_t)(splits * pl.n_out) * sizeof(T), &pv));
+        int rc = mdhip_alloc((size_t)(splits * pl.n_out) * sizeof(int64_t), &pi);
+        if (rc != MDHIP_OK) { mdhip_free(pv); return rc; }
+        k_arg_rows_vec<IsMax, T, false><<<(unsigned)(pl.n_out * splits), MD_BLOCK, 0, st>>>(pl, (const T *)x->data, splits, chunk, (T *)pv, (int64_t *)pi);
+        k_arg_rows_finish<IsMax, T><<<(unsigned)ceil_div(pl.n_out, MD_BLOCK), MD_BLOCK, 0, st>>>(pl, (const T *)pv, (const int64_t *)pi, splits, (int64_t *)out->data);
+        rc = MD_LAUNCH_CHECK("argreduce(rows,vec,split)");
+        mdhip_free(pv);
+        mdhip_free(pi);
+        return rc;
+      }
+    }
     if (pl.n_red >= 512 && pl.n_out < (1ll << 30)) {
       k_arg_block<IsMax, T><<<(unsigned)pl.n_out, MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, (int64_t *)out->data);
       return MD_LAUNCH_CHECK("argreduce(block)");

@@ -718,6 +718,10 @@ def _binary(ufunc, code, a, b, out=None):
             res = _lazy_node(_lz.BINARY, code, (a, b), pcdt, shape, odt)
             if res is not None:
                 return res
+    if a_arr:
+        a = _straighten(a)
+    if b_arr:
+        b = _straighten(b)
     da = _operand_desc(a, shape, 0 if a_arr else _scalar_code(a, cdt))
     db = _operand_desc(b, shape, 0 if b_arr else _scalar_code(b, cdt))
     if out is None:
@@ -737,6 +741,17 @@ def _binary(ufunc, code, a, b, out=None):
         _lib().binary(code, da, db, tmp.desc(), _DTYPE_CODES[cdt])
         _copy_into(out, tmp)
     return out
+
+
+def _straighten(x):
+    """A large operand whose LAST axis is strided but another axis is unit-stride (x.T, swapaxes)
+    would be read one element per cache line by the generic kernel; the tiled transposing copy
+    runs ~3x faster than that, and the streaming kernel then takes the contiguous copy."""
+    st = x._strides
+    if x.size >= (1 << 16) and len(st) >= 2 and x._expr is None and st[-1] not in (0, 1) and 1 in st[-3:-1] \
+            and x.shape[-1] >= 32:
+        return copy(x)
+    return x
 
 
 def _check_int_power(b):
@@ -1149,12 +1164,65 @@ def _reduce(code, a, axis, keepdims, out_dtype):
                 fshape = tuple(n for i, n in enumerate(a.shape) if not (mask >> i) & 1)
                 fused = fused._view(fused._offset, fshape, _c_strides(fshape))
             return fused
+    if a.size >= _RESHAPE_REDUCE_MIN and a.ndim >= 2:
+        staged = _staged_reduce(code, a, axes, mask, keepdims, kshape, out_dtype)
+        if staged is not None:
+            return staged
     res = DeviceArray.empty(kshape, out_dtype)
     _lib().reduce(code, a.desc(), res.desc(), mask)
     if not keepdims:
         fshape = tuple(n for i, n in enumerate(a.shape) if not (mask >> i) & 1)
         res = res._view(res._offset, fshape, _c_strides(fshape))
     return res
+
+
+_RESHAPE_REDUCE_MIN = 1 << 18
+
+
+def _dense_flat_view(a):
+    """1-D view over the block of an array whose axes are a permutation of a dense layout
+    (x.T, swapaxes, ...): an order-free reduction may walk memory linearly instead."""
+    dims = sorted((st, n) for st, n in zip(a._strides, a.shape) if n != 1)
+    acc = 1
+    for st, n in dims:
+        if st != acc:
+            return None
+        acc *= n
+    return a._view(a._offset, (a.size,), (1,))
+
+
+def _staged_reduce(code, a, axes, mask, keepdims, kshape, out_dtype):
+    """Large reductions the single-pass kernels walk badly, re-expressed through the fast ones
+    (sum/prod/max/min/any/all are associative and commutative; float sums already differ
+    from NumPy's pairwise order by rounding only):
+      * every axis of a permuted-but-dense view  -> the same reduction over linear memory;
+      * several separated groups of axes (e.g. (0, 2), the batch-norm (0, 2, 3)) -> one group
+        per pass, innermost first, so every pass has ONE reduced extent (row or column walk)."""
+    nd = a.ndim
+    if mask == (1 << nd) - 1:
+        if a.is_c_contiguous:
+            return None
+        flat = _dense_flat_view(a)
+        if flat is None:
+            return None
+        r = _reduce(code, flat, None, False, out_dtype)
+        shape = kshape if keepdims else ()
+        return r._view(r._offset, shape, _c_strides(shape))
+    runs = []  # maximal runs of adjacent reduced axes (extent-1 axes do not separate them)
+    for ax in sorted(axes):
+        if runs and builtins_all(a.shape[k] == 1 or (mask >> k) & 1 for k in range(runs[-1][-1] + 1, ax)):
+            runs[-1].append(ax)
+        else:
+            runs.append([ax])
+    if len(runs) < 2:
+        return None
+    cur = a
+    for run in reversed(runs):
+        cur = _reduce(code, cur, tuple(run), True, out_dtype)
+    if not keepdims:
+        fshape = tuple(n for i, n in enumerate(a.shape) if not (mask >> i) & 1)
+        cur = cur._view(cur._offset, fshape, _c_strides(fshape))
+    return cur
 
 
 def _fused_reduce(code, a, mask, kshape, out_dtype):

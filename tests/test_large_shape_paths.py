@@ -1,0 +1,130 @@
+"""Parity of the kernels and host-side re-expressions that serve LARGE, awkwardly laid-out
+calls (scripts/shape_sweep.py found them walking memory badly): vectorised argmax/argmin over
+rows and over columns (incl. ties and NaNs: first occurrence, as np.argmax), 16-byte run gathers,
+the tiled transposing copy, reductions of permuted-dense views and of separated axis groups.
+Twins: the CPU double checks the host logic, the GPU run checks the HIP kernels."""
+import numpy as np
+import pytest
+
+from minidiff_amd import ndarray as nd
+
+gpu = pytest.mark.gpu
+
+
+def _twin(fn):
+    def cpu(lib, on_gpu):
+        if on_gpu:
+            pytest.skip("other twin")
+        fn()
+
+    def dev(lib, on_gpu):
+        assert on_gpu
+        fn()
+    return cpu, gpu(dev)
+
+
+def _arg():
+    rng = np.random.default_rng(0)
+    for dt in (np.float32, np.float64, np.int64, np.int32):
+        for shape in ((300, 4096), (2048, 1024), (3, 70000), (1500, 260)):
+            if np.dtype(dt).kind == "f":
+                h = rng.standard_normal(shape).astype(dt)
+                h[rng.integers(0, shape[0], 40), rng.integers(0, shape[1], 40)] = np.nan      # first NaN wins
+                h[:, 7] = np.inf if shape[1] > 7 else h[:, 7]
+            else:
+                h = rng.integers(-5, 5, shape).astype(dt)                                      # many ties: first wins
+            d = nd.asarray(h)
+            for axis in (0, 1, None):
+                assert np.array_equal(np.asarray(nd.argmax(d, axis=axis)), np.argmax(h, axis=axis)), (dt, shape, axis)
+                assert np.array_equal(np.asarray(nd.argmin(d, axis=axis)), np.argmin(h, axis=axis)), (dt, shape, axis)
+        # unaligned row starts (odd row length) and a sliced view
+        h = rng.standard_normal((257, 4099)).astype(dt) if np.dtype(dt).kind == "f" else rng.integers(-9, 9, (257, 4099)).astype(dt)
+        d = nd.asarray(h)
+        assert np.array_equal(np.asarray(nd.argmax(d, axis=1)), np.argmax(h, axis=1))
+        assert np.array_equal(np.asarray(nd.argmax(d[:, 3:], axis=1)), np.argmax(h[:, 3:], axis=1))
+        assert np.array_equal(np.asarray(nd.argmin(d[1:, :4096], axis=0)), np.argmin(h[1:, :4096], axis=0))
+    allneg = np.full((4, 2048), -np.inf, dtype=np.float32)
+    assert np.array_equal(np.asarray(nd.argmax(nd.asarray(allneg), axis=1)), np.zeros(4, dtype=np.int64))
+
+
+test_arg_cpu, test_arg_gpu = _twin(_arg)
+
+
+def _gather():
+    rng = np.random.default_rng(1)
+    for dt in (np.float32, np.float64, np.int64, np.bool_):
+        h = (rng.standard_normal((500, 256)) * 10).astype(dt)
+        d = nd.asarray(h)
+        idx = rng.integers(-500, 500, (333,))
+        assert np.array_equal(np.asarray(d[nd.asarray(idx)]), h[idx])                         # rows: 16-B runs
+        idx2 = rng.integers(0, 500, (7, 11))
+        assert np.array_equal(np.asarray(d[nd.asarray(idx2)]), h[idx2])
+        assert np.array_equal(np.asarray(d[nd.asarray(idx), 4:]), h[idx, 4:])                 # still aligned runs (f32: 16 B)
+        assert np.array_equal(np.asarray(d[nd.asarray(idx), 3:]), h[idx, 3:])                 # unaligned: element path
+        assert np.array_equal(np.asarray(d[:, nd.asarray(idx[:100] % 256)]), h[:, idx[:100] % 256])   # index on the last axis
+        t = nd.asarray(np.ascontiguousarray(h.reshape(50, 10, 256)))
+        i3 = rng.integers(0, 10, (6,))
+        assert np.array_equal(np.asarray(t[:, nd.asarray(i3)]), h.reshape(50, 10, 256)[:, i3])
+    d = nd.asarray(np.zeros((500, 256), dtype=np.float32))
+    with pytest.raises(IndexError):
+        d[nd.asarray(np.array([0, 500] * 40))]
+
+
+test_gather_cpu, test_gather_gpu = _twin(_gather)
+
+
+def _transposed():
+    rng = np.random.default_rng(2)
+    for dt in (np.float32, np.float64, np.int64):
+        h = (rng.standard_normal((300, 1000)) * 7).astype(dt)
+        w = (rng.standard_normal((1000, 300)) * 7).astype(dt)
+        d, e = nd.asarray(h), nd.asarray(w)
+        assert np.array_equal(np.asarray(nd.copy(d.T)), h.T)
+        assert np.array_equal(np.asarray(nd.add(e, d.T)), w + h.T)                            # straightened operand
+        assert np.array_equal(np.asarray(nd.multiply(d.T, d.T)), h.T * h.T)
+        assert np.array_equal(np.asarray(nd.negative(d.T)), -h.T)
+        t = (rng.standard_normal((5, 130, 70)) * 3).astype(dt)
+        td = nd.asarray(t)
+        assert np.array_equal(np.asarray(nd.copy(nd.swapaxes(td, 1, 2))), np.swapaxes(t, 1, 2))   # batched
+        assert np.array_equal(np.asarray(nd.copy(td.T)), t.T)                                      # full reversal: generic
+        assert np.array_equal(np.asarray(nd.copy(d[:, ::3].T)), h[:, ::3].T)                       # strided both ways
+        if np.dtype(dt).kind == "f":
+            np.testing.assert_allclose(np.asarray(nd.exp(nd.multiply(d.T, 0.01))), np.exp(h.T * dt(0.01)), rtol=1e-6)
+            assert np.asarray(nd.astype(d.T, np.float64)).dtype == np.float64
+            assert np.array_equal(np.asarray(nd.astype(d.T, np.float64)), h.T.astype(np.float64))
+
+
+test_transposed_cpu, test_transposed_gpu = _twin(_transposed)
+
+
+def _staged():
+    rng = np.random.default_rng(3)
+    h = rng.standard_normal((40, 130, 96)).astype(np.float32)
+    d = nd.asarray(h)
+    hi = rng.integers(-50, 50, (40, 130, 96))
+    di = nd.asarray(hi)
+    for axis in ((0, 2), (2, 0), (0, 1), (1, 2), 1, None):
+        for keep in (False, True):
+            ref = h.astype(np.float64).sum(axis=axis, keepdims=keep)          # f32 accumulation: error scales with sum|x|
+            bound = 2e-6 * np.abs(h).astype(np.float64).sum(axis=axis, keepdims=keep).max()
+            assert np.abs(np.asarray(nd.sum(d, axis=axis, keepdims=keep)) - ref).max() <= bound
+            assert np.array_equal(np.asarray(nd.max(d, axis=axis, keepdims=keep)), h.max(axis=axis, keepdims=keep))
+            assert np.array_equal(np.asarray(nd.sum(di, axis=axis, keepdims=keep)), hi.sum(axis=axis, keepdims=keep))   # ints: exact
+            assert np.array_equal(np.asarray(nd.any(nd.greater(d, 3.5), axis=axis, keepdims=keep)), (h > 3.5).any(axis=axis, keepdims=keep))
+    np.testing.assert_allclose(np.asarray(nd.mean(d, axis=(0, 2))), h.astype(np.float64).mean(axis=(0, 2)), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(np.asarray(nd.std(d, axis=(0, 2))), h.std(axis=(0, 2)), rtol=2e-5)
+    q = rng.standard_normal((12, 20, 1, 33, 37)).astype(np.float64)      # extent-1 axis between two reduced ones
+    qd = nd.asarray(q)
+    np.testing.assert_allclose(np.asarray(nd.sum(qd, axis=(0, 1, 3))), q.sum(axis=(0, 1, 3)), rtol=1e-12)
+    np.testing.assert_allclose(np.asarray(nd.sum(qd, axis=(0, 3, 4))), q.sum(axis=(0, 3, 4)), rtol=1e-12)
+    # permuted-dense views reduced over everything
+    for view, ref in ((d.T, h.T), (nd.swapaxes(d, 0, 1), np.swapaxes(h, 0, 1)), (nd.transpose(d, (1, 2, 0)), np.transpose(h, (1, 2, 0)))):
+        np.testing.assert_allclose(float(np.asarray(nd.sum(view))), float(ref.astype(np.float64).sum()), rtol=1e-5)
+        assert float(np.asarray(nd.max(view))) == ref.max()
+        assert np.asarray(nd.sum(view, keepdims=True)).shape == (1, 1, 1)
+    assert int(np.asarray(nd.sum(di.T))) == int(hi.sum())
+    np.testing.assert_allclose(float(np.asarray(nd.sum(d[:, ::2].T))), float(h[:, ::2].astype(np.float64).sum()), rtol=1e-5)   # gaps: not dense
+    assert nd.argmax(d.T).item() == int(np.argmax(h.T))     # order matters: never flattened
+
+
+test_staged_cpu, test_staged_gpu = _twin(_staged)
