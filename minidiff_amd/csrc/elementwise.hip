@@ -325,6 +325,29 @@ struct HipExec {
       else k_unary_fast<F, Tc, To, Tx, false><<<md_grid_for(work), MD_BLOCK, 0, st>>>(fx, sx, (To *)out->data, g.rows, g.inner);
       return MD_LAUNCH_CHECK("unary(fast)");
     }
+    // dtype conversions (astype, definitions.py:429-432; raw .astype, tensor.py:105): the same streaming
+    // kernel with the SOURCE storage type as the load type
+    if constexpr (md_same<F, UCopy>::value) {
+      if (!x->is_scalar && x->dtype != md_dtype_of<Tx>::value && fast_geom(it, 1, &g) && fast_aligned<To>(out->data)) {
+        const int64_t work = g.rows * (g.inner >> 2) + (g.rows == 1 ? 4 : 0);
+#define MD_CAST_FROM(S)                                                                                                   \
+        {                                                                                                                 \
+          FastOp<S> fs;                                                                                                   \
+          if (fast_operand<S>(it, 0, x, g, &fs)) {                                                                        \
+            k_unary_fast<F, Tc, To, S, false><<<md_grid_for(work), MD_BLOCK, 0, st>>>(fs, sx, (To *)out->data, g.rows, g.inner); \
+            return MD_LAUNCH_CHECK("unary(fast,cast)");                                                                   \
+          }                                                                                                               \
+        }
+        switch (x->dtype) {
+          case MDHIP_F32: MD_CAST_FROM(float) break;
+          case MDHIP_F64: MD_CAST_FROM(double) break;
+          case MDHIP_I64: MD_CAST_FROM(int64_t) break;
+          case MDHIP_I32: MD_CAST_FROM(int32_t) break;
+          case MDHIP_BOOL: MD_CAST_FROM(b8) break;
+        }
+#undef MD_CAST_FROM
+      }
+    }
     int64_t B, R, Cn, xb, xc;
     if (!x->is_scalar && it.total >= (1 << 14) && tr_geom(it, 0, 1, &B, &R, &Cn, &xb, &xc)) {
       const int tr = (int)((R + 63) / 64), tc = (int)((Cn + 63) / 64);

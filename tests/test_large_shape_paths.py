@@ -128,3 +128,20 @@ def _staged():
 
 
 test_staged_cpu, test_staged_gpu = _twin(_staged)
+
+
+def _casts():
+    rng = np.random.default_rng(4)
+    dts = (np.float32, np.float64, np.int64, np.int32, np.bool_)
+    for shape in ((300, 1000), (70001,), (5, 7, 44)):
+        for src in dts:
+            h = (rng.standard_normal(shape) * 50).astype(src)
+            d = nd.asarray(h)
+            for dst in dts:
+                got = np.asarray(nd.astype(d, dst))
+                assert got.dtype == np.dtype(dst)
+                assert np.array_equal(got, h.astype(dst)), (shape, src, dst)
+            assert np.array_equal(np.asarray(nd.astype(d[1:], np.float64)), h[1:].astype(np.float64))   # unaligned start
+
+
+test_casts_cpu, test_casts_gpu = _twin(_casts)
