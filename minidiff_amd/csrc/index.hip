@@ -12,6 +12,10 @@
 // sequentially when the plan is small and otherwise run order-preserving rounds
 // (per destination the smallest unfinished position goes first) — no float
 // atomics, no write races. Integer ADD uses atomics (exact in any order).
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "md_hip.h"
 
 extern "C" int mdhip_alloc(size_t, void **);
@@ -50,12 +54,13 @@ __global__ void __launch_bounds__(MD_BLOCK) k_gather_vec(mdhip_index_plan pl, in
   }
 }
 
-__global__ void __launch_bounds__(MD_BLOCK) k_check_bounds(mdhip_index_plan pl, int64_t total, int *err) {
+// `step` > 1: only every step-th position is probed (run plans: no index varies along the last axis)
+__global__ void __launch_bounds__(MD_BLOCK) k_check_bounds(mdhip_index_plan pl, int64_t count, int64_t step, int *err) {
   const int64_t gs = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gs) {
     int64_t pos[MDHIP_MAX_NDIM];
     bool oob = false;
-    md_plan_offset(pl, i, pos, &oob);
+    md_plan_offset(pl, i * step, pos, &oob);
     if (oob) *err = 1;
   }
 }
@@ -148,6 +153,167 @@ static int read_flag(int *dflag, int *host) {
   return md_hip_check(hipStreamSynchronize(md_stream()), "hipStreamSynchronize");
 }
 
+// ---- contiguous runs: order at ROW granularity -------------------------------------------
+// The backward of a[idx] (np.add.at(grad, idx, g), definitions.py:186-189) and a[idx] = v move
+// whole rows: the plan's last axis is a contiguous run of the destination that no index array
+// varies along. Then the duplicates question is per ROW: destinations of two plan rows are
+// either identical or disjoint (checked on the host: every outer stride is a multiple of a
+// common g >= run length). The P row offsets are sorted stably (rocPRIM radix sort, so equal
+// destinations keep plan order) and each destination row is produced by ONE pass that applies
+// its contributions in that order: np.add.at's accumulation order / last-write-wins for SET,
+// O(P log P + P*L) whatever the multiplicities.
+constexpr uint64_t RUN_BIAS = 1ull << 62;
+__global__ void __launch_bounds__(MD_BLOCK) k_run_offsets(mdhip_index_plan pl, int64_t P, int64_t L, uint64_t *keys, int64_t *ids) {
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gs) {
+    int64_t pos[MDHIP_MAX_NDIM];
+    bool oob = false;
+    keys[p] = (uint64_t)(md_plan_offset(pl, p * L, pos, &oob) + (int64_t)RUN_BIAS);
+    ids[p] = p;
+  }
+}
+template <class T, int MODE>
+__global__ void __launch_bounds__(MD_BLOCK) k_run_apply(mdhip_index_plan pl, int64_t P, int64_t L, const uint64_t *__restrict__ keys,
+                                                       const int64_t *__restrict__ ids, T *dst, ValDesc v, T s) {
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x, total = P * L;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
+    const int64_t q = i / L, c = i - q * L;
+    const uint64_t key = keys[q];
+    if (q > 0 && keys[q - 1] == key) continue;  // not the first contribution of its destination row
+    T *d = dst + ((int64_t)(key - RUN_BIAS) + c);
+    auto value = [&](int64_t p) -> T {
+      if (v.is_scalar) return s;
+      int64_t lin = p, vo = c * v.strides[pl.ndim - 1];
+      for (int dd = pl.ndim - 2; dd >= 0; --dd) {
+        const int64_t e = pl.shape[dd], qq = lin / e;
+        vo += (lin - qq * e) * v.strides[dd];
+        lin = qq;
+      }
+      return ((const T *)v.p)[vo];
+    };
+    if constexpr (MODE == MDHIP_SCATTER_ADD) {
+      T acc = *d;
+      for (int64_t q2 = q; q2 < P && keys[q2] == key; ++q2) acc = BAdd::apply(acc, value(ids[q2]));
+      *d = acc;
+    } else {
+      int64_t q2 = q;
+      while (q2 + 1 < P && keys[q2 + 1] == key) ++q2;
+      *d = value(ids[q2]);
+    }
+  }
+}
+// the same with 16-B units when rows, destination and values are 16-B aligned
+template <class T, int MODE>
+__global__ void __launch_bounds__(MD_BLOCK) k_run_apply_vec(mdhip_index_plan pl, int64_t P, int64_t L, const uint64_t *__restrict__ keys,
+                                                           const int64_t *__restrict__ ids, T *dst, ValDesc v, T s) {
+  constexpr int V = 16 / sizeof(T);
+  const int64_t Lv = L / V, gs = (int64_t)gridDim.x * blockDim.x, total = P * Lv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
+    const int64_t q = i / Lv, c = (i - q * Lv) * V;
+    const uint64_t key = keys[q];
+    if (q > 0 && keys[q - 1] == key) continue;
+    MdVec<T, V> *d = reinterpret_cast<MdVec<T, V> *>(dst + ((int64_t)(key - RUN_BIAS) + c));
+    auto value = [&](int64_t p) -> MdVec<T, V> {
+      MdVec<T, V> r;
+      if (v.is_scalar) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) r.v[j] = s;
+        return r;
+      }
+      int64_t lin = p, vo = c;
+      for (int dd = pl.ndim - 2; dd >= 0; --dd) {
+        const int64_t e = pl.shape[dd], qq = lin / e;
+        vo += (lin - qq * e) * v.strides[dd];
+        lin = qq;
+      }
+      return *reinterpret_cast<const MdVec<T, V> *>((const T *)v.p + vo);
+    };
+    if constexpr (MODE == MDHIP_SCATTER_ADD) {
+      MdVec<T, V> acc = *d;
+      for (int64_t q2 = q; q2 < P && keys[q2] == key; ++q2) {
+        const MdVec<T, V> t = value(ids[q2]);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc.v[j] = BAdd::apply(acc.v[j], t.v[j]);
+      }
+      *d = acc;
+    } else {
+      int64_t q2 = q;
+      while (q2 + 1 < P && keys[q2 + 1] == key) ++q2;
+      *d = value(ids[q2]);
+    }
+  }
+}
+template <class T> static bool run_vectorisable(const mdhip_index_plan *pl, int64_t L, const void *dst, const ValDesc &v) {
+  constexpr int V = 16 / sizeof(T);
+  if (V < 2 || (L % V) || ((uintptr_t)dst & 15)) return false;
+  const int nd = pl->ndim;
+  for (int d = 0; d < nd - 1; ++d)
+    if (pl->shape[d] > 1 && (pl->src_strides[d] % V)) return false;
+  for (int k = 0; k < pl->n_idx; ++k)
+    if (pl->idx_extent[k] > 1 && (pl->idx_mult[k] % V)) return false;
+  if (!v.is_scalar) {
+    if (v.strides[nd - 1] != 1 || ((uintptr_t)v.p & 15)) return false;
+    for (int d = 0; d < nd - 1; ++d)
+      if (pl->shape[d] > 1 && (v.strides[d] % V)) return false;
+  }
+  return true;
+}
+static int64_t gcd64(int64_t a, int64_t b) {
+  if (a < 0) a = -a;
+  if (b < 0) b = -b;
+  while (b) { const int64_t t = a % b; a = b; b = t; }
+  return a;
+}
+static bool run_geometry(const mdhip_index_plan *pl, int64_t *L, int64_t *P) {
+  const int nd = pl->ndim;
+  if (nd < 1) return false;
+  *L = pl->shape[nd - 1];
+  if (*L < 8 || pl->src_strides[nd - 1] != 1) return false;
+  for (int k = 0; k < pl->n_idx; ++k)
+    if (pl->idx_strides[k][nd - 1] != 0) return false;
+  int64_t g = 0;
+  *P = 1;
+  for (int d = 0; d < nd - 1; ++d) {
+    *P *= pl->shape[d];
+    if (pl->shape[d] > 1) g = gcd64(g, pl->src_strides[d]);
+  }
+  for (int k = 0; k < pl->n_idx; ++k)
+    if (pl->idx_extent[k] > 1) g = gcd64(g, pl->idx_mult[k]);
+  return (g == 0 || g >= *L) && *P < (1ll << 31);
+}
+template <class T, int MODE>
+static int scatter_runs(const mdhip_index_plan *pl, int64_t P, int64_t L, void *dst, const ValDesc &v, T s) {
+  hipStream_t st = md_stream();
+  void *keys = nullptr, *ids = nullptr, *tmp = nullptr;
+  size_t tmp_bytes = 0;
+  uint64_t *k0 = nullptr;
+  int64_t *i0 = nullptr;
+  if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k0, i0, i0, (size_t)P, 0, 64, st) != hipSuccess)
+    return md_fail(MDHIP_ERUNTIME, "scatter(runs): sort sizing failed");
+  MD_TRY(mdhip_alloc((size_t)P * 16, &keys));
+  int rc = mdhip_alloc((size_t)P * 16, &ids);
+  if (rc == MDHIP_OK) rc = mdhip_alloc(tmp_bytes ? tmp_bytes : 1, &tmp);
+  if (rc == MDHIP_OK) {
+    uint64_t *kin = (uint64_t *)keys, *kout = kin + P;
+    int64_t *iin = (int64_t *)ids, *iout = iin + P;
+    k_run_offsets<<<md_grid_for(P), MD_BLOCK, 0, st>>>(*pl, P, L, kin, iin);
+    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, iin, iout, (size_t)P, 0, 64, st) != hipSuccess) {
+      (void)hipGetLastError();
+      rc = md_fail(MDHIP_ERUNTIME, "scatter(runs): sort failed");
+    } else {
+      if (run_vectorisable<T>(pl, L, dst, v))
+        k_run_apply_vec<T, MODE><<<md_grid_for(P * (L / (16 / (int64_t)sizeof(T)))), MD_BLOCK, 0, st>>>(*pl, P, L, kout, iout, (T *)dst, v, s);
+      else
+        k_run_apply<T, MODE><<<md_grid_for(P * L), MD_BLOCK, 0, st>>>(*pl, P, L, kout, iout, (T *)dst, v, s);
+      rc = MD_LAUNCH_CHECK("scatter(runs)");
+    }
+  }
+  if (tmp) mdhip_free(tmp);
+  if (ids) mdhip_free(ids);
+  mdhip_free(keys);
+  return rc;
+}
+
 // order-preserving rounds (see k_bid / k_apply)
 template <class T, int MODE>
 static int scatter_ordered(const mdhip_index_plan *pl, int64_t total, void *dst, const ValDesc &v, T s) {
@@ -191,7 +357,12 @@ static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, c
     else k_scatter_serial<T, MDHIP_SCATTER_ADD><<<1, 64, 0, st>>>(*pl, total, (T *)dst, v, s);
     return MD_LAUNCH_CHECK("scatter(serial)");
   }
-  if (mode == MDHIP_SCATTER_SET) return scatter_ordered<T, MDHIP_SCATTER_SET>(pl, total, dst, v, s);
+  int64_t L = 0, P = 0;
+  const bool runs = run_geometry(pl, &L, &P);
+  if (mode == MDHIP_SCATTER_SET) {
+    if (runs) return scatter_runs<T, MDHIP_SCATTER_SET>(pl, P, L, dst, v, s);
+    return scatter_ordered<T, MDHIP_SCATTER_SET>(pl, total, dst, v, s);
+  }
   if constexpr (md_same<T, uint8_t>::value) {
     k_scatter_serial<T, MDHIP_SCATTER_ADD><<<1, 64, 0, st>>>(*pl, total, (T *)dst, v, s);
     return MD_LAUNCH_CHECK("scatter(add,bool)");
@@ -199,6 +370,7 @@ static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, c
     k_scatter_add_int<T><<<md_grid_for(total), MD_BLOCK, 0, st>>>(*pl, total, (T *)dst, v, s);
     return MD_LAUNCH_CHECK("scatter(add,int)");
   } else {
+    if (runs) return scatter_runs<T, MDHIP_SCATTER_ADD>(pl, P, L, dst, v, s);
     return scatter_ordered<T, MDHIP_SCATTER_ADD>(pl, total, dst, v, s);
   }
 }
@@ -367,7 +539,11 @@ int mdhip_scatter(const mdhip_index_plan *pl, void *dst, int dtype, const mdhip_
   void *flag = nullptr;
   MD_TRY(mdhip_alloc(sizeof(int), &flag));
   (void)hipMemsetAsync(flag, 0, sizeof(int), md_stream());
-  k_check_bounds<<<md_grid_for(total), MD_BLOCK, 0, md_stream()>>>(*pl, total, (int *)flag);
+  {
+    int64_t L = 0, P = 0;
+    if (run_geometry(pl, &L, &P)) k_check_bounds<<<md_grid_for(P), MD_BLOCK, 0, md_stream()>>>(*pl, P, L, (int *)flag);
+    else k_check_bounds<<<md_grid_for(total), MD_BLOCK, 0, md_stream()>>>(*pl, total, 1, (int *)flag);
+  }
   int bad = 0;
   int rc = read_flag((int *)flag, &bad);
   mdhip_free(flag);

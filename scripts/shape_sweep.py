@@ -25,6 +25,8 @@ def main():
     zd = nd.asarray(rng.standard_normal((R // 2, Cc)))
     zi = nd.asarray(rng.integers(-100, 100, (R // 2, Cc)))
     idx = nd.asarray(rng.integers(0, R, (R,)))
+    perm = nd.asarray(rng.permutation(R))
+    idx64 = nd.asarray(rng.integers(0, 64, (R,)))
     E = 4 * R * Cc
     e0, e1 = C.c_void_p(), C.c_void_p()
     lib.event_create(C.byref(e0)); lib.event_create(C.byref(e1))
@@ -55,6 +57,9 @@ def main():
         ("sum(zt.T) full, transposed view", lambda: nd.sum(zt.T), E),
         ("sum f64 all", lambda: nd.sum(zd), 8 * zd.size),
         ("gather rows z[idx]", lambda: z[idx], 2 * E),
+        ("index_add rows (unique idx)", lambda: nd.index_add(w, perm, z), 3 * E),
+        ("index_add rows (dups, 64 dests)", lambda: nd.index_add(w, idx64, z), 2 * E),
+        ("z[perm] = w  (row assignment)", lambda: z.__setitem__(perm, w), 2 * E),
         ("prod axis=1", lambda: nd.prod(z, axis=1), E),
         ("any(z > 3)", lambda: nd.any(nd.greater(z, 3)), E + z.size + z.size),
     ]

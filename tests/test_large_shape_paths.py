@@ -145,3 +145,54 @@ def _casts():
 
 
 test_casts_cpu, test_casts_gpu = _twin(_casts)
+
+
+def _scatter():
+    """np.add.at / a[idx] = v at row granularity: duplicates accumulate in index order (bit-exact
+    float sums), the last duplicate wins for assignment."""
+    rng = np.random.default_rng(6)
+    for dt in (np.float32, np.float64, np.int64):
+        for n_idx, hi in ((3000, 40), (2000, 5000), (1500, 1)):       # heavy duplication / nearly unique / all equal
+            R, Cn = 5000 if hi > 100 else 64, 48
+            base = (rng.standard_normal((R, Cn)) * 3).astype(dt)
+            vals = (rng.standard_normal((n_idx, Cn)) * 3).astype(dt)
+            idx = rng.integers(-hi, hi, (n_idx,)) if hi <= R else rng.integers(0, R, (n_idx,))
+            exp = base.copy()
+            np.add.at(exp, idx, vals)
+            d = nd.asarray(base)
+            nd.index_add(d, nd.asarray(idx), nd.asarray(vals))
+            assert np.array_equal(np.asarray(d), exp), (dt, n_idx, hi)
+            exp = base.copy()
+            exp[idx] = vals
+            d = nd.asarray(base)
+            d[nd.asarray(idx)] = nd.asarray(vals)
+            assert np.array_equal(np.asarray(d), exp), (dt, n_idx, hi, "set")
+        base = (rng.standard_normal((300, 64)) * 3).astype(dt)
+        idx = rng.integers(0, 300, (500,))
+        for vals in ((rng.standard_normal((500, 1)) * 3).astype(dt), (rng.standard_normal((1, 64)) * 3).astype(dt), dt(2.5) if dt != np.int64 else 3):
+            exp = base.copy()
+            np.add.at(exp, idx, vals)
+            d = nd.asarray(base)
+            nd.index_add(d, nd.asarray(idx), nd.asarray(vals) if isinstance(vals, np.ndarray) else vals)
+            assert np.array_equal(np.asarray(d), exp)
+        # a slice of the last axis (run shorter than the row), and an index on a middle axis
+        exp = base.copy()
+        vals = (rng.standard_normal((500, 37)) * 3).astype(dt)
+        np.add.at(exp[:, 5:42], idx, vals)
+        d = nd.asarray(base)
+        nd.index_add(d[:, 5:42], nd.asarray(idx), nd.asarray(vals))
+        assert np.array_equal(np.asarray(d), exp)
+        t = (rng.standard_normal((20, 30, 40)) * 3).astype(dt)
+        i3 = rng.integers(0, 30, (200,))
+        v3 = (rng.standard_normal((20, 200, 40)) * 3).astype(dt)
+        exp = t.copy()
+        np.add.at(exp, (slice(None), i3), v3)
+        d = nd.asarray(t)
+        nd.index_add(d, (slice(None), nd.asarray(i3)), nd.asarray(v3))
+        assert np.array_equal(np.asarray(d), exp)
+    d = nd.asarray(np.zeros((50, 64), dtype=np.float32))
+    with pytest.raises(IndexError):
+        nd.index_add(d, nd.asarray(np.array([0, 50] * 100)), nd.asarray(np.ones((200, 64), dtype=np.float32)))
+
+
+test_scatter_cpu, test_scatter_gpu = _twin(_scatter)
