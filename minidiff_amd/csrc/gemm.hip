@@ -38,13 +38,14 @@ struct GemmArgs {
   int64_t M, N, K;
   int64_t a_bs, a_ms, a_ks, b_bs, b_ks, b_ns, c_bs, c_ms, c_ns;
   int tiles_m, tiles_n;
+  int vec_ok;  // EDGE kernels: operands are 16-B aligned, so a fully inside vector may be loaded whole
 };
 
 // Tile loaders for a ROWS x BK operand tile, NT threads, 16 B per thread per pass.
 // KC = the operand's k axis is the contiguous one in memory (row-major A, or B given as Bt).
 template <int ROWS, int BK, int NT, bool KC, bool EDGE>
 __device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t rs, int64_t ks, int64_t row0, int64_t k0,
-                                          int64_t rows, int64_t K, f32x4 (&r)[ROWS * BK / (4 * NT)]) {
+                                          int64_t rows, int64_t K, f32x4 (&r)[ROWS * BK / (4 * NT)], bool vec_ok = true) {
   constexpr int PASSES = ROWS * BK / (4 * NT);
   constexpr int TPR = BK / 4;            // KC: threads per row
   constexpr int RPP = NT / TPR;          // KC: rows per pass
@@ -59,10 +60,18 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t r
     if constexpr (!EDGE) {
       r[i] = *reinterpret_cast<const f32x4 *>(P + (row0 + row) * rs + (k0 + k) * ks);
     } else {
+      // ragged M/N/K: a vector that lies wholly inside the operand is still ONE 16-B load (only the
+      // last tile row/column and the K tail take the per-element path); unaligned operands always do
+      const int64_t rr0 = row0 + row, kk0 = k0 + k;
+      const bool inside = KC ? (rr0 < rows && kk0 + 3 < K) : (kk0 < K && rr0 + 3 < rows);
+      if (vec_ok && inside) {
+        r[i] = *reinterpret_cast<const f32x4 *>(P + rr0 * rs + kk0 * ks);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t rr = row0 + row + (KC ? 0 : j), kk = k0 + k + (KC ? j : 0);
-        r[i][j] = (rr < rows && kk < K) ? P[rr * rs + kk * ks] : 0.0f;
+        for (int j = 0; j < 4; ++j) {
+          const int64_t rr = rr0 + (KC ? 0 : j), kk = kk0 + (KC ? j : 0);
+          r[i][j] = (rr < rows && kk < K) ? P[rr * rs + kk * ks] : 0.0f;
+        }
       }
     }
   }
@@ -123,13 +132,14 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_mfma(GemmArgs g) {
   // inside the MFMA stream of tile kt the wave (step 0/1) writes tile kt+1 to the
   // other LDS buffer and (step 2) issues the global loads of tile kt+2 - so staging
   // costs no MFMA time of its own and the loads have ~6 steps (>3000 cycles) to land.
-  load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, 0, g.M, g.K, ra);
-  load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, 0, g.N, g.K, rb);
+  const bool vec_ok = g.vec_ok != 0;
+  load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, 0, g.M, g.K, ra, vec_ok);
+  load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, 0, g.N, g.K, rb, vec_ok);
   store_tile<BM, BK, NT, A_KC>(As[0], ra);
   store_tile<BN, BK, NT, B_KC>(Bs[0], rb);
   if (nk > 1) {
-    load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, BK, g.M, g.K, ra);
-    load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, BK, g.N, g.K, rb);
+    load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, BK, g.M, g.K, ra, vec_ok);
+    load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, BK, g.N, g.K, rb, vec_ok);
   }
   __syncthreads();
 
@@ -153,8 +163,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_mfma(GemmArgs g) {
       if (kk == 0 && more) store_tile<BM, BK, NT, A_KC>(As[cur ^ 1], ra);
       if (kk == 2 && more) store_tile<BN, BK, NT, B_KC>(Bs[cur ^ 1], rb);
       if (kk == 4 && more2) {
-        load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 2) * BK, g.M, g.K, ra);
-        load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 2) * BK, g.N, g.K, rb);
+        load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 2) * BK, g.M, g.K, ra, vec_ok);
+        load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 2) * BK, g.N, g.K, rb, vec_ok);
       }
       // pin the order: staging and prefetch are issued ahead of this step's MFMAs
       __builtin_amdgcn_sched_barrier(0);
@@ -213,6 +223,7 @@ template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC>
 static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
   ga.tiles_m = (int)((ga.M + BM - 1) / BM);
   ga.tiles_n = (int)((ga.N + BN - 1) / BN);
+  ga.vec_ok = edge ? 0 : 1;  // `edge` on entry = operands not 16-B aligned
   edge = edge || (ga.M % BM) || (ga.N % BN) || (ga.K % BK);
   dim3 grid((unsigned)(ga.tiles_m * ga.tiles_n), 1, (unsigned)batch);
   if (edge) k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, true><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);

@@ -196,3 +196,37 @@ def _scatter():
 
 
 test_scatter_cpu, test_scatter_gpu = _twin(_scatter)
+
+
+def _ragged_matmul(shapes=((1000, 784, 512), (257, 130, 515), (1031, 1028, 260), (300, 17, 301), (2000, 1000, 1500))):
+    """Shapes that are not multiples of the block tile (guarded edge variant of the MFMA kernel:
+    whole 16-B loads wherever a vector lies inside the operand), all three layouts of the
+    matmul backward, aligned and unaligned row strides."""
+    rng = np.random.default_rng(7)
+    for (M, K, N) in shapes:
+        a = rng.standard_normal((M, K)).astype(np.float32)
+        b = rng.standard_normal((K, N)).astype(np.float32)
+        ref = a.astype(np.float64) @ b.astype(np.float64)
+        scale = np.abs(ref).max()
+        A, B = nd.asarray(a), nd.asarray(b)
+        At, Bt = nd.asarray(np.ascontiguousarray(a.T)), nd.asarray(np.ascontiguousarray(b.T))
+        for x, y in ((A, B), (A, Bt.T), (At.T, B), (At.T, Bt.T)):
+            got = np.asarray(nd.matmul(x, y))
+            assert got.shape == (M, N)
+            assert np.abs(got - ref).max() / scale < 2e-6, (M, K, N)
+        # views with an offset (rows no longer 16-B aligned) and a batch
+        got = np.asarray(nd.matmul(A[1:, 1:], B[1:, 3:]))
+        assert np.abs(got - a[1:, 1:].astype(np.float64) @ b[1:, 3:].astype(np.float64)).max() / scale < 2e-6
+    t = rng.standard_normal((3, 200, 96)).astype(np.float32)
+    u = rng.standard_normal((3, 96, 130)).astype(np.float32)
+    got = np.asarray(nd.matmul(nd.asarray(t), nd.asarray(u)))
+    assert np.abs(got - t.astype(np.float64) @ u.astype(np.float64)).max() / np.abs(got).max() < 2e-6
+
+
+_, test_ragged_matmul_gpu = _twin(_ragged_matmul)
+
+
+def test_ragged_matmul_cpu(lib, on_gpu):
+    if on_gpu:
+        pytest.skip("other twin")
+    _ragged_matmul(shapes=((257, 130, 515), (300, 17, 301)))   # the CPU double's GEMM is a plain triple loop
