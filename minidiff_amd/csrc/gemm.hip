@@ -25,6 +25,9 @@
 
 #include "md_hip.h"
 
+extern "C" int mdhip_alloc(size_t, void **);
+extern "C" int mdhip_free(void *);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -39,6 +42,9 @@ struct GemmArgs {
   int64_t a_bs, a_ms, a_ks, b_bs, b_ks, b_ns, c_bs, c_ms, c_ns;
   int tiles_m, tiles_n;
   int vec_ok;  // EDGE kernels: operands are 16-B aligned, so a fully inside vector may be loaded whole
+  // split-K (gridDim.y > 1): block y multiplies k in [y*k_chunk, (y+1)*k_chunk) into its own
+  // partial C (C + y*c_split), summed afterwards in split order by k_gemm_splitk_sum
+  int64_t k_chunk, c_split;
 };
 
 // Tile loaders for a ROWS x BK operand tile, NT threads, 16 B per thread per pass.
@@ -109,9 +115,11 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_mfma(GemmArgs g) {
   const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const int64_t bz = blockIdx.z;
-  const float *A = g.A + bz * g.a_bs;
-  const float *B = g.B + bz * g.b_bs;
-  float *C = g.C + bz * g.c_bs;
+  const int64_t ks0 = (int64_t)blockIdx.y * g.k_chunk;
+  const float *A = g.A + bz * g.a_bs + ks0 * g.a_ks;
+  const float *B = g.B + bz * g.b_bs + ks0 * g.b_ks;
+  float *C = g.C + bz * g.c_bs + (int64_t)blockIdx.y * g.c_split;
+  const int64_t Kl = (gridDim.y > 1 && g.K - ks0 > g.k_chunk) ? g.k_chunk : g.K - ks0;  // this block's k extent
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -126,20 +134,20 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_mfma(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   f32x4 ra[BM * BK / (4 * NT)], rb[BN * BK / (4 * NT)];
-  const int64_t nk = (g.K + BK - 1) / BK;
+  const int64_t nk = (Kl + BK - 1) / BK;
   // A tile rows = m (row stride a_ms), B tile rows = n (row stride b_ns)
   // Pipeline: LDS buffer `cur` holds tile kt, registers hold tile kt+1 (landed), and
   // inside the MFMA stream of tile kt the wave (step 0/1) writes tile kt+1 to the
   // other LDS buffer and (step 2) issues the global loads of tile kt+2 - so staging
   // costs no MFMA time of its own and the loads have ~6 steps (>3000 cycles) to land.
   const bool vec_ok = g.vec_ok != 0;
-  load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, 0, g.M, g.K, ra, vec_ok);
-  load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, 0, g.N, g.K, rb, vec_ok);
+  load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, 0, g.M, Kl, ra, vec_ok);
+  load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, 0, g.N, Kl, rb, vec_ok);
   store_tile<BM, BK, NT, A_KC>(As[0], ra);
   store_tile<BN, BK, NT, B_KC>(Bs[0], rb);
   if (nk > 1) {
-    load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, BK, g.M, g.K, ra, vec_ok);
-    load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, BK, g.N, g.K, rb, vec_ok);
+    load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, BK, g.M, Kl, ra, vec_ok);
+    load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, BK, g.N, Kl, rb, vec_ok);
   }
   __syncthreads();
 
@@ -163,8 +171,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_mfma(GemmArgs g) {
       if (kk == 0 && more) store_tile<BM, BK, NT, A_KC>(As[cur ^ 1], ra);
       if (kk == 2 && more) store_tile<BN, BK, NT, B_KC>(Bs[cur ^ 1], rb);
       if (kk == 4 && more2) {
-        load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 2) * BK, g.M, g.K, ra, vec_ok);
-        load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 2) * BK, g.N, g.K, rb, vec_ok);
+        load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 2) * BK, g.M, Kl, ra, vec_ok);
+        load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 2) * BK, g.N, Kl, rb, vec_ok);
       }
       // pin the order: staging and prefetch are issued ahead of this step's MFMAs
       __builtin_amdgcn_sched_barrier(0);
@@ -219,15 +227,57 @@ __global__ void __launch_bounds__(256) k_gemm_generic(MdGemm g) {
   if (row < g.M && col < g.N) C[row * g.c_ms + col * g.c_ns] = acc;
 }
 
+// C[b][m][n] = sum over splits (in split order: deterministic) of the partial products
+__global__ void __launch_bounds__(MD_BLOCK) k_gemm_splitk_sum(const float *__restrict__ part, int splits, int64_t batch, int64_t M, int64_t N,
+                                                             float *C, int64_t c_bs, int64_t c_ms, int64_t c_ns) {
+  const int64_t total = batch * M * N, gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
+    float acc = part[i];
+    for (int s = 1; s < splits; ++s) acc += part[(int64_t)s * total + i];
+    const int64_t b = i / (M * N), r = i - b * (M * N), m = r / N, n = r - m * N;
+    C[b * c_bs + m * c_ms + n * c_ns] = acc;
+  }
+}
+
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC>
 static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
   ga.tiles_m = (int)((ga.M + BM - 1) / BM);
   ga.tiles_n = (int)((ga.N + BN - 1) / BN);
   ga.vec_ok = edge ? 0 : 1;  // `edge` on entry = operands not 16-B aligned
   edge = edge || (ga.M % BM) || (ga.N % BN) || (ga.K % BK);
-  dim3 grid((unsigned)(ga.tiles_m * ga.tiles_n), 1, (unsigned)batch);
+  // split-K: a grid that cannot give every CU a block (skinny M or N with a long K, e.g. a
+  // 64 x 4096 batch through a 4096 x 4096 layer) is widened along k; >= 512 k per split
+  const int64_t tiles = (int64_t)ga.tiles_m * ga.tiles_n * batch;
+  int64_t splits = 1;
+  static const int splitk_mode = [] { const char *e = getenv("MDHIP_GEMM_SPLITK"); return e ? atoi(e) : 1; }();
+  if (splitk_mode && tiles < MD_NUM_CUS && ga.K >= 1024) {
+    splits = (2 * MD_NUM_CUS + tiles - 1) / tiles;
+    if (splits > ga.K / 512) splits = ga.K / 512;
+    if (splits > 64) splits = 64;
+  }
+  ga.k_chunk = ga.K;
+  ga.c_split = 0;
+  void *partial = nullptr;
+  GemmArgs out = ga;
+  if (splits > 1) {
+    ga.k_chunk = ((ga.K + splits - 1) / splits + BK - 1) / BK * BK;
+    splits = (ga.K + ga.k_chunk - 1) / ga.k_chunk;
+    MD_TRY(mdhip_alloc((size_t)(splits * batch * ga.M * ga.N) * sizeof(float), &partial));
+    ga.C = (float *)partial;
+    ga.c_bs = ga.M * ga.N; ga.c_ms = ga.N; ga.c_ns = 1;
+    ga.c_split = batch * ga.M * ga.N;
+    edge = edge || (ga.k_chunk % BK) || (ga.K % ga.k_chunk % BK);
+  }
+  dim3 grid((unsigned)(ga.tiles_m * ga.tiles_n), (unsigned)splits, (unsigned)batch);
   if (edge) k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, true><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
   else k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, false><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
+  if (splits > 1) {
+    k_gemm_splitk_sum<<<md_grid_for(batch * ga.M * ga.N), MD_BLOCK, 0, md_stream()>>>((const float *)partial, (int)splits, batch, ga.M, ga.N,
+                                                                                   out.C, out.c_bs, out.c_ms, out.c_ns);
+    int rc = MD_LAUNCH_CHECK("matmul(f32 mfma, split-k)");
+    mdhip_free(partial);
+    return rc;
+  }
   return MD_LAUNCH_CHECK("matmul(f32 mfma)");
 }
 

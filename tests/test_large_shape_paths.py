@@ -226,6 +226,33 @@ def _ragged_matmul(shapes=((1000, 784, 512), (257, 130, 515), (1031, 1028, 260),
 _, test_ragged_matmul_gpu = _twin(_ragged_matmul)
 
 
+@gpu
+def test_skinny_matmul_split_k_gpu(lib, on_gpu):
+    """Few output tiles and a long k (small batch through a wide layer): the grid is widened along
+    k, partial products are summed in split order — same result on every run, within fp32 of f64."""
+    assert on_gpu
+    rng = np.random.default_rng(8)
+    for (M, K, N) in ((64, 4096, 4096), (4096, 4096, 64), (32, 2048, 300), (100, 5000, 70), (128, 1024, 128)):
+        a = rng.standard_normal((M, K)).astype(np.float32)
+        b = rng.standard_normal((K, N)).astype(np.float32)
+        ref = a.astype(np.float64) @ b.astype(np.float64)
+        A, B = nd.asarray(a), nd.asarray(b)
+        At, Bt = nd.asarray(np.ascontiguousarray(a.T)), nd.asarray(np.ascontiguousarray(b.T))
+        first = None
+        for x, y in ((A, B), (A, Bt.T), (At.T, B)):
+            got = np.asarray(nd.matmul(x, y))
+            assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6, (M, K, N)
+            if first is None:
+                first = got
+                assert np.array_equal(np.asarray(nd.matmul(x, y)), first)      # deterministic
+    t = rng.standard_normal((2, 64, 2048)).astype(np.float32)
+    u = rng.standard_normal((2, 2048, 128)).astype(np.float32)
+    got = np.asarray(nd.matmul(nd.asarray(t), nd.asarray(u)))
+    ref = t.astype(np.float64) @ u.astype(np.float64)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
+
+
+
 def test_ragged_matmul_cpu(lib, on_gpu):
     if on_gpu:
         pytest.skip("other twin")
