@@ -19,8 +19,9 @@
 //   step ahead in a register double buffer; one barrier per k-step.
 //   Workgroup ids are remapped so the 8 XCDs each own a contiguous band of
 //   output tiles (per-XCD L2 locality on the shared A row panel).
-// other dtypes / ragged or unaligned shapes: guarded edge variant of the same
-// kernel (f32) or a plain LDS-tiled kernel (f64 / ints; test-sized problems).
+// ragged or unaligned shapes: guarded edge variant of the same kernel; few tiles and a long k:
+// split-K with a deterministic split-order sum. f64: the same scheme on v_mfma_f64_16x16x4_f64
+// (k_gemm_f64_mfma). Integers / tiny problems: a plain LDS-tiled kernel.
 #include <stdlib.h>
 
 #include "md_hip.h"
@@ -313,6 +314,180 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
   }
 }
 
+
+// ======================= f64: v_mfma_f64_16x16x4_f64 ===========================================
+// Same staging scheme as the f32 kernel (k-major LDS double buffer, registers hold the tile in
+// flight, fragment reads one step ahead), 16x16x4 MFMA tiles: lane l feeds A[l&15][k=l>>4] /
+// B[k=l>>4][l&15]; the accumulator holds C[(l>>4)+4r][l&15], r=0..3 (the f64 map differs from
+// every other MFMA shape, cdna_hip_programming.md "Fragment layout"). Bound: 78.6 TFLOP/s.
+// Serves the reference's own tests, which run in float64 (tests/test_ops.py:311-323, (10,30)@(30,20)
+// and up) and any f64 user; the fp32 headline never comes here.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+constexpr int LDP64 = 16;  // LDS row pad (doubles): the two 16-lane k-groups of a half-wave land on disjoint banks
+
+struct GemmArgs64 {
+  const double *A, *B;
+  double *C;
+  int64_t M, N, K;
+  int64_t a_bs, a_ms, a_ks, b_bs, b_ks, b_ns, c_bs, c_ms, c_ns;
+  int tiles_m, tiles_n;
+  int vec_ok;
+};
+
+template <int ROWS, int BK, int NT, bool KC, bool EDGE>
+__device__ __forceinline__ void load_tile64(const double *__restrict__ P, int64_t rs, int64_t ks, int64_t row0, int64_t k0,
+                                            int64_t rows, int64_t K, f64x2 (&r)[ROWS * BK / (2 * NT)], bool vec_ok) {
+  constexpr int PASSES = ROWS * BK / (2 * NT);
+  constexpr int TPR = BK / 2, RPP = NT / TPR;   // KC: threads per row / rows per pass
+  constexpr int TPK = ROWS / 2, KPP = NT / TPK; // !KC: threads per k-row / k-rows per pass
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < PASSES; ++i) {
+    int row, k;
+    if constexpr (KC) { row = t / TPR + RPP * i; k = (t % TPR) * 2; }
+    else { k = t / TPK + KPP * i; row = (t % TPK) * 2; }
+    if constexpr (!EDGE) {
+      r[i] = *reinterpret_cast<const f64x2 *>(P + (row0 + row) * rs + (k0 + k) * ks);
+    } else {
+      const int64_t rr0 = row0 + row, kk0 = k0 + k;
+      const bool inside = KC ? (rr0 < rows && kk0 + 1 < K) : (kk0 < K && rr0 + 1 < rows);
+      if (vec_ok && inside) {
+        r[i] = *reinterpret_cast<const f64x2 *>(P + rr0 * rs + kk0 * ks);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int64_t rr = rr0 + (KC ? 0 : j), kk = kk0 + (KC ? j : 0);
+          r[i][j] = (rr < rows && kk < K) ? P[rr * rs + kk * ks] : 0.0;
+        }
+      }
+    }
+  }
+}
+template <int ROWS, int BK, int NT, bool KC>
+__device__ __forceinline__ void store_tile64(double (*S)[ROWS + LDP64], const f64x2 (&r)[ROWS * BK / (2 * NT)]) {
+  constexpr int PASSES = ROWS * BK / (2 * NT);
+  constexpr int TPR = BK / 2, RPP = NT / TPR, TPK = ROWS / 2, KPP = NT / TPK;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < PASSES; ++i) {
+    if constexpr (KC) {
+      const int row = t / TPR + RPP * i, k = (t % TPR) * 2;
+      S[k][row] = r[i][0];
+      S[k + 1][row] = r[i][1];
+    } else {
+      const int k = t / TPK + KPP * i, row = (t % TPK) * 2;
+      *reinterpret_cast<f64x2 *>(&S[k][row]) = r[i];
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool EDGE>
+__global__ void __launch_bounds__(64 * WM * WN) k_gemm_f64_mfma(GemmArgs64 g) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int WTM = BM / (16 * WM), WTN = BN / (16 * WN);
+  __shared__ double As[2][BK][BM + LDP64];
+  __shared__ double Bs[2][BK][BN + LDP64];
+  const int nblk = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t bz = blockIdx.z;
+  const double *A = g.A + bz * g.a_bs;
+  const double *B = g.B + bz * g.b_bs;
+  double *C = g.C + bz * g.c_bs;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l16 = lane & 15, h = lane >> 4;
+  const bool vec_ok = g.vec_ok != 0;
+
+  f64x4 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+
+  f64x2 ra[BM * BK / (2 * NT)], rb[BN * BK / (2 * NT)];
+  const int64_t nk = (g.K + BK - 1) / BK;
+  load_tile64<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, 0, g.M, g.K, ra, vec_ok);
+  load_tile64<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, 0, g.N, g.K, rb, vec_ok);
+  store_tile64<BM, BK, NT, A_KC>(As[0], ra);
+  store_tile64<BN, BK, NT, B_KC>(Bs[0], rb);
+  if (nk > 1) {
+    load_tile64<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, BK, g.M, g.K, ra, vec_ok);
+    load_tile64<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, BK, g.N, g.K, rb, vec_ok);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
+    double fa[2][WTM], fb[2][WTN];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) fa[0][i] = As[cur][h][wm * (WTM * 16) + i * 16 + l16];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) fb[0][j] = Bs[cur][h][wn * (WTN * 16) + j * 16 + l16];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      const int c = (kk >> 2) & 1;
+      if (kk + 4 < BK) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) fa[c ^ 1][i] = As[cur][kk + 4 + h][wm * (WTM * 16) + i * 16 + l16];
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) fb[c ^ 1][j] = Bs[cur][kk + 4 + h][wn * (WTN * 16) + j * 16 + l16];
+      }
+      if (kk == 0 && more) store_tile64<BM, BK, NT, A_KC>(As[cur ^ 1], ra);
+      if (kk == 4 && more) store_tile64<BN, BK, NT, B_KC>(Bs[cur ^ 1], rb);
+      if (kk == 8 && more2) {
+        load_tile64<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 2) * BK, g.M, g.K, ra, vec_ok);
+        load_tile64<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 2) * BK, g.N, g.K, rb, vec_ok);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // C/D of the f64 16x16 tile: col = lane&15, row = (lane>>4) + 4*r
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int64_t col = n0 + wn * (WTN * 16) + j * 16 + l16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wm * (WTM * 16) + i * 16 + h + 4 * r;
+        if (!EDGE || (row < g.M && col < g.N)) C[row * g.c_ms + col * g.c_ns] = acc[i][j][r];
+      }
+    }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+static int launch_f64(GemmArgs64 ga, int64_t batch, bool edge) {
+  constexpr int BK = 16;
+  ga.tiles_m = (int)((ga.M + BM - 1) / BM);
+  ga.tiles_n = (int)((ga.N + BN - 1) / BN);
+  ga.vec_ok = edge ? 0 : 1;
+  edge = edge || (ga.M % BM) || (ga.N % BN) || (ga.K % BK);
+  dim3 grid((unsigned)(ga.tiles_m * ga.tiles_n), 1, (unsigned)batch);
+  if (edge) k_gemm_f64_mfma<BM, BN, BK, 2, 2, A_KC, B_KC, true><<<grid, 256, 0, md_stream()>>>(ga);
+  else k_gemm_f64_mfma<BM, BN, BK, 2, 2, A_KC, B_KC, false><<<grid, 256, 0, md_stream()>>>(ga);
+  return MD_LAUNCH_CHECK("matmul(f64 mfma)");
+}
+template <bool A_KC, bool B_KC>
+static int launch_f64_pick(const GemmArgs64 &ga, int64_t batch, bool edge) {
+  const int64_t t128 = ((ga.M + 127) / 128) * ((ga.N + 127) / 128) * batch;
+  if (t128 >= 2 * MD_NUM_CUS) return launch_f64<128, 128, A_KC, B_KC>(ga, batch, edge);
+  return launch_f64<64, 64, A_KC, B_KC>(ga, batch, edge);
+}
+
 struct HipExec {
   template <class T> static int gemm(const MdGemm &g) {
     if (g.batch > 65535) return md_fail(MDHIP_EVALUE, "matmul: batch extent %lld exceeds 65535", (long long)g.batch);
@@ -339,6 +514,28 @@ struct HipExec {
         if (A_KC && !B_KC) return launch_mfma<true, false>(ga, g.batch, edge);
         if (!A_KC && B_KC) return launch_mfma<false, true>(ga, g.batch, edge);
         return launch_mfma<false, false>(ga, g.batch, edge);
+      }
+    }
+    if constexpr (md_same<T, double>::value) {
+      const bool a_kc = g.a_ks == 1 || g.K == 1, a_mc = g.a_ms == 1 || g.M == 1;
+      const bool b_kc = g.b_ks == 1 || g.K == 1, b_nc = g.b_ns == 1 || g.N == 1;
+      static const int f64_mfma = [] { const char *e = getenv("MDHIP_GEMM_F64_MFMA"); return e ? atoi(e) : 1; }();
+      if (f64_mfma && g.M * g.N >= 64 * 64 && g.K >= 8 && (a_kc || a_mc) && (b_kc || b_nc) && g.M * g.N < (1ll << 40)) {
+        GemmArgs64 ga;
+        ga.A = (const double *)g.a; ga.B = (const double *)g.b; ga.C = (double *)g.c;
+        ga.M = g.M; ga.N = g.N; ga.K = g.K;
+        ga.a_bs = g.a_bs; ga.a_ms = g.a_ms; ga.a_ks = g.a_ks;
+        ga.b_bs = g.b_bs; ga.b_ks = g.b_ks; ga.b_ns = g.b_ns;
+        ga.c_bs = g.c_bs; ga.c_ms = g.c_ms; ga.c_ns = g.c_ns;
+        ga.tiles_m = ga.tiles_n = 0;
+        const bool A_KC = a_kc && !(a_mc && g.a_ks != 1), B_KC = b_kc && !(b_nc && g.b_ks != 1);
+        auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+        bool edge = !al16(g.a) || !al16(g.b);
+        edge = edge || ((A_KC ? g.a_ms : g.a_ks) & 1) || ((B_KC ? g.b_ns : g.b_ks) & 1) || (g.a_bs & 1) || (g.b_bs & 1);
+        if (A_KC && B_KC) return launch_f64_pick<true, true>(ga, g.batch, edge);
+        if (A_KC && !B_KC) return launch_f64_pick<true, false>(ga, g.batch, edge);
+        if (!A_KC && B_KC) return launch_f64_pick<false, true>(ga, g.batch, edge);
+        return launch_f64_pick<false, false>(ga, g.batch, edge);
       }
     }
     dim3 grid((unsigned)((g.N + 15) / 16), (unsigned)((g.M + 15) / 16), (unsigned)g.batch);

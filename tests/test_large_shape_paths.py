@@ -257,3 +257,31 @@ def test_ragged_matmul_cpu(lib, on_gpu):
     if on_gpu:
         pytest.skip("other twin")
     _ragged_matmul(shapes=((257, 130, 515), (300, 17, 301)))   # the CPU double's GEMM is a plain triple loop
+
+
+@gpu
+def test_f64_matmul_mfma_gpu(lib, on_gpu):
+    """float64 matmul on the f64 matrix cores: the three layouts of the matmul backward, aligned,
+    ragged and offset operands, batched; exact integer data pins the lane maps."""
+    assert on_gpu
+    rng = np.random.default_rng(9)
+    for (M, K, N) in ((256, 256, 256), (1024, 512, 768), (130, 70, 515), (64, 64, 64), (2048, 64, 2048), (10, 30, 20), (300, 17, 301)):
+        a = rng.standard_normal((M, K))
+        b = rng.standard_normal((K, N))
+        ref = a @ b
+        A, B = nd.asarray(a), nd.asarray(b)
+        At, Bt = nd.asarray(np.ascontiguousarray(a.T)), nd.asarray(np.ascontiguousarray(b.T))
+        for x, y in ((A, B), (A, Bt.T), (At.T, B), (At.T, Bt.T)):
+            got = np.asarray(nd.matmul(x, y))
+            assert got.dtype == np.float64 and got.shape == (M, N)
+            assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-14, (M, K, N)
+        if M > 64:
+            got = np.asarray(nd.matmul(A[1:, 1:], B[1:, 3:]))
+            assert np.abs(got - a[1:, 1:] @ b[1:, 3:]).max() / np.abs(ref).max() < 1e-14
+        ai = rng.integers(-8, 8, (M, K)).astype(np.float64)        # exact in any order: every element must match
+        bi = rng.integers(-8, 8, (K, N)).astype(np.float64)
+        assert np.array_equal(np.asarray(nd.matmul(nd.asarray(ai), nd.asarray(bi))), ai @ bi)
+    t = rng.standard_normal((3, 200, 96))
+    u = rng.standard_normal((3, 96, 130))
+    got = np.asarray(nd.matmul(nd.asarray(t), nd.asarray(u)))
+    assert np.abs(got - t @ u).max() / np.abs(got).max() < 1e-14
