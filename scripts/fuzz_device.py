@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the device array library against NumPy: random shapes, dtypes, strided /
+transposed / broadcast views and argument forms for the elementwise, reduction, arg-reduction,
+indexing and matmul entry points. Integers / bools / indices must match bit for bit, floats within
+a few ulp-scaled tolerances.   python scripts/fuzz_device.py [n_cases] [seed] [--big]
+Runs on whatever library the process binds (the GPU product by default; tests bind the CPU double)."""
+import os
+import sys
+import traceback
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from minidiff_amd import ndarray as nd  # noqa: E402
+
+DTYPES = [np.float32, np.float64, np.int64, np.int32, np.bool_]
+
+
+def rand_array(rng, shape, dt):
+    if np.dtype(dt).kind == "f":
+        a = (rng.standard_normal(shape) * rng.choice([0.1, 1.0, 30.0])).astype(dt)
+        if a.size and rng.random() < 0.15:
+            flat = a.reshape(-1)
+            flat[rng.integers(0, flat.size, builtins_max(1, flat.size // 50))] = rng.choice([np.nan, np.inf, -np.inf, 0.0, -0.0])
+        return a
+    if np.dtype(dt).kind == "b":
+        return rng.random(shape) < 0.5
+    return rng.integers(-9, 10, shape).astype(dt)
+
+
+builtins_max = max
+
+
+def rand_shape(rng, big):
+    nd_ = int(rng.integers(0, 5))
+    if big and rng.random() < 0.5:
+        return tuple(int(x) for x in rng.choice([1, 2, 3, 17, 64, 130, 257, 1024], nd_ or 1))[:3]
+    return tuple(int(x) for x in rng.integers(0 if rng.random() < 0.05 else 1, 9, nd_))
+
+
+def rand_view(rng, h, d):
+    """Apply the same random view ops to host and device arrays."""
+    for _ in range(int(rng.integers(0, 3))):
+        if h.ndim == 0:
+            break
+        k = rng.integers(0, 4)
+        if k == 0 and h.ndim >= 2:
+            perm = tuple(int(x) for x in rng.permutation(h.ndim))
+            h, d = h.transpose(perm), nd.transpose(d, perm)
+        elif k == 1:
+            ax = int(rng.integers(0, h.ndim))
+            n = h.shape[ax]
+            if n >= 2:
+                start, step = int(rng.integers(0, 2)), int(rng.choice([1, 2, -1]))
+                sl = [slice(None)] * h.ndim
+                sl[ax] = slice(None, None, step) if step < 0 else slice(start, None, step)
+                h, d = h[tuple(sl)], d[tuple(sl)]
+        elif k == 2 and h.ndim < 4:
+            ax = int(rng.integers(0, h.ndim + 1))
+            h, d = np.expand_dims(h, ax), nd.expand_dims(d, ax)
+        elif k == 3 and h.ndim >= 2:
+            a0, a1 = (int(x) for x in rng.choice(h.ndim, 2, replace=False))
+            h, d = np.swapaxes(h, a0, a1), nd.swapaxes(d, a0, a1)
+    return h, d
+
+
+def broadcastable(rng, shape):
+    s = list(shape)
+    for i in range(len(s)):
+        if rng.random() < 0.3:
+            s[i] = 1
+    cut = int(rng.integers(0, len(s) + 1))
+    return tuple(s[cut:])
+
+
+def close(got, exp, what):
+    got = np.asarray(got)
+    exp = np.asarray(exp)
+    assert got.shape == exp.shape, f"{what}: shape {got.shape} vs {exp.shape}"
+    assert got.dtype == exp.dtype, f"{what}: dtype {got.dtype} vs {exp.dtype}"
+    if exp.dtype.kind in "biu":
+        assert np.array_equal(got, exp), f"{what}: integer/bool mismatch"
+        return
+    tol = 3e-6 if exp.dtype == np.float32 else 1e-13
+    with np.errstate(all="ignore"):
+        same_special = np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(np.isinf(got), np.isinf(exp))
+        assert same_special, f"{what}: nan/inf pattern differs"
+        fin = np.isfinite(exp)
+        if fin.any():
+            err = np.abs(got[fin].astype(np.float64) - exp[fin].astype(np.float64))
+            bound = tol * np.maximum(np.abs(exp[fin]).astype(np.float64), 1e-30) + tol * 1e-2
+            assert (err <= bound).all(), f"{what}: max rel err {(err / np.maximum(np.abs(exp[fin]), 1e-30)).max():.3e}"
+        inf = np.isinf(exp)
+        assert np.array_equal(got[inf], exp[inf]), f"{what}: inf sign"
+
+
+UNARY = ["absolute", "negative", "sign", "ceil", "floor", "sin", "cos", "tanh", "exp", "sqrt", "logical_not", "copy"]
+BINARY = ["add", "subtract", "multiply", "true_divide", "maximum", "minimum", "less", "greater_equal", "equal", "not_equal",
+          "logical_and", "logical_or", "floor_divide", "mod", "power"]
+REDUCE = ["sum", "prod", "max", "min", "any", "all", "mean"]
+
+
+def one_case(rng, big):
+    kind = rng.choice(["unary", "binary", "where", "reduce", "arg", "gather", "scatter", "matmul", "astype"])
+    dt = DTYPES[int(rng.integers(0, len(DTYPES)))]
+    shape = rand_shape(rng, big)
+    h = rand_array(rng, shape, dt)
+    d = nd.asarray(h)
+    h, d = rand_view(rng, h, d)
+    with np.errstate(all="ignore"):
+        if kind == "unary":
+            name = str(rng.choice(UNARY))
+            if name in ("sin", "cos", "tanh", "exp", "sqrt") and h.dtype.kind == "f":
+                h = np.clip(np.nan_to_num(h, nan=0.5, posinf=3.0, neginf=-3.0), -20, 20).astype(h.dtype)
+                d = nd.asarray(h)
+            if name == "negative" and h.dtype == np.bool_:
+                return
+            if name == "sign" and h.dtype == np.bool_:
+                return
+            if name in ("sin", "cos", "tanh", "exp", "sqrt", "ceil", "floor") and h.dtype == np.bool_:
+                return  # NumPy answers in float16, which the backend does not carry
+            close(getattr(nd, name)(d), getattr(np, name)(h), f"{name}{h.shape}{h.dtype}")
+        elif kind == "binary":
+            name = str(rng.choice(BINARY))
+            dt2 = DTYPES[int(rng.integers(0, len(DTYPES)))]
+            if rng.random() < 0.25:
+                h2 = d2 = rng.choice([2, -3, 0.5, 2.0, True]).item()
+            else:
+                h2 = rand_array(rng, broadcastable(rng, h.shape), dt2)
+                d2 = nd.asarray(h2)
+            if name in ("floor_divide", "mod", "power", "true_divide"):
+                if np.asarray(h2).dtype.kind in "biu" or np.asarray(h).dtype.kind in "biu" or name == "power":
+                    return  # division by zero / negative integer powers: covered by the golden cases
+            if name in ("subtract",) and (np.asarray(h).dtype == np.bool_ and np.asarray(h2).dtype == np.bool_):
+                return
+            if rng.random() < 0.5:
+                h, h2, d, d2 = h2, h, d2, d
+            if not isinstance(d, nd.DeviceArray) and not isinstance(d2, nd.DeviceArray):
+                return
+            close(getattr(nd, name)(d, d2), getattr(np, name)(h, h2), f"{name} {np.shape(h)}{np.asarray(h).dtype} {np.shape(h2)}{np.asarray(h2).dtype}")
+        elif kind == "where":
+            c = rng.random(h.shape) < 0.5
+            b = rand_array(rng, broadcastable(rng, h.shape), dt)
+            close(nd.where(nd.asarray(c), d, nd.asarray(b)), np.where(c, h, b), f"where {h.shape}{dt}")
+        elif kind == "reduce":
+            name = str(rng.choice(REDUCE))
+            if h.ndim == 0 or h.size == 0:
+                return
+            if rng.random() < 0.3:
+                axis = None
+            else:
+                k = int(rng.integers(1, h.ndim + 1))
+                axis = tuple(int(x) for x in rng.choice(h.ndim, k, replace=False))
+                if len(axis) == 1 and rng.random() < 0.5:
+                    axis = axis[0] - (h.ndim if rng.random() < 0.3 else 0)
+            keep = bool(rng.random() < 0.4)
+            if h.dtype.kind == "f":
+                h = np.nan_to_num(h, nan=0.25, posinf=4.0, neginf=-4.0).astype(h.dtype)
+                if name == "prod":
+                    h = (np.sign(h) * (0.9 + 0.2 * np.abs(np.tanh(h)))).astype(h.dtype)
+                d = nd.asarray(h)
+            exp = getattr(np, name)(h, axis=axis, keepdims=keep)
+            got = getattr(nd, name)(d, axis=axis, keepdims=keep)
+            if exp.dtype.kind == "f" and name in ("sum", "mean", "prod"):
+                got, exp = np.asarray(got), np.asarray(exp)
+                assert got.shape == exp.shape and got.dtype == exp.dtype, f"{name} {h.shape} axis={axis}: {got.shape}/{got.dtype} vs {exp.shape}/{exp.dtype}"
+                scale = np.abs(h.astype(np.float64)).sum() + 1.0 if name != "prod" else np.abs(exp).max() + 1.0
+                tol = 2e-6 if h.dtype == np.float32 else 1e-13
+                assert np.abs(got.astype(np.float64) - exp.astype(np.float64)).max() <= tol * scale * (50 if name == "prod" else 1), f"{name} {h.shape}{h.dtype} axis={axis}"
+            else:
+                close(got, exp, f"{name} {h.shape}{h.dtype} axis={axis} keep={keep}")
+        elif kind == "arg":
+            if h.size == 0:
+                return
+            axis = None if (h.ndim == 0 or rng.random() < 0.3) else int(rng.integers(-h.ndim, h.ndim))
+            name = str(rng.choice(["argmax", "argmin"]))
+            close(getattr(nd, name)(d, axis=axis), getattr(np, name)(h, axis=axis), f"{name} {h.shape}{h.dtype} axis={axis}")
+        elif kind == "gather":
+            if h.ndim == 0 or h.size == 0:
+                return
+            ax = int(rng.integers(0, h.ndim))
+            ish = rand_shape(rng, False)[:2]
+            idx = rng.integers(-h.shape[ax], h.shape[ax], ish)
+            key = [slice(None)] * h.ndim
+            key[ax] = idx
+            dkey = list(key)
+            dkey[ax] = nd.asarray(idx)
+            close(d[tuple(dkey)], h[tuple(key)], f"gather {h.shape}{h.dtype} ax={ax} idx{idx.shape}")
+        elif kind == "scatter":
+            if h.ndim == 0 or h.size == 0 or h.dtype == np.bool_:
+                return
+            h = np.ascontiguousarray(h)
+            d = nd.asarray(h)
+            ax = int(rng.integers(0, h.ndim))
+            n = int(rng.integers(1, 12 if not big else 3000))
+            idx = rng.integers(-h.shape[ax], h.shape[ax], (n,))
+            vshape = h.shape[:ax] + (n,) + h.shape[ax + 1:]
+            vals = rand_array(rng, vshape, h.dtype)
+            if h.dtype.kind == "f":
+                vals = np.nan_to_num(vals, nan=1.0, posinf=2.0, neginf=-2.0).astype(h.dtype)
+                h = np.nan_to_num(h, nan=1.0, posinf=2.0, neginf=-2.0).astype(h.dtype)
+                d = nd.asarray(h)
+            key = tuple([slice(None)] * ax + [idx])
+            dkey = tuple([slice(None)] * ax + [nd.asarray(idx)])
+            exp = h.copy()
+            if rng.random() < 0.5:
+                np.add.at(exp, key, vals)
+                nd.index_add(d, dkey, nd.asarray(vals))
+            else:
+                exp[key] = vals
+                d[dkey] = nd.asarray(vals)
+            got = np.asarray(d)
+            assert np.array_equal(got, exp), f"scatter {h.shape}{h.dtype} ax={ax} n={n}"
+        elif kind == "matmul":
+            fdt = np.float32 if rng.random() < 0.5 else np.float64
+            lim = 300 if big else 40
+            M, K, N = (int(x) for x in rng.integers(1, lim, 3))
+            a = rng.standard_normal((M, K)).astype(fdt)
+            b = rng.standard_normal((K, N)).astype(fdt)
+            A, B = nd.asarray(a), nd.asarray(b)
+            if rng.random() < 0.5:
+                A = nd.asarray(np.ascontiguousarray(a.T)).T
+            if rng.random() < 0.5:
+                B = nd.asarray(np.ascontiguousarray(b.T)).T
+            got = np.asarray(nd.matmul(A, B))
+            ref = a.astype(np.float64) @ b.astype(np.float64)
+            tol = 3e-6 if fdt == np.float32 else 1e-13
+            assert got.dtype == fdt and np.abs(got - ref).max() <= tol * (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)).max() + 1e-30, f"matmul {M}x{K}x{N} {fdt}"
+        elif kind == "astype":
+            to = DTYPES[int(rng.integers(0, len(DTYPES)))]
+            if h.dtype.kind == "f" and np.dtype(to).kind in "iu":
+                h = np.nan_to_num(h, nan=1.0, posinf=2.0, neginf=-2.0).astype(h.dtype)
+                d = nd.asarray(h)
+            close(nd.astype(d, to), h.astype(to), f"astype {h.shape} {h.dtype}->{np.dtype(to)}")
+
+
+def main(n=2000, seed=0, big=False):
+    fails = 0
+    for i in range(n):
+        rng = np.random.default_rng([seed, i])
+        try:
+            one_case(rng, big)
+        except AssertionError as e:
+            fails += 1
+            print(f"FAIL case {i} (seed {seed}): {e}", flush=True)
+        except Exception as e:  # the two sides must also agree on raising
+            fails += 1
+            print(f"ERROR case {i} (seed {seed}): {type(e).__name__}: {e}", flush=True)
+            if fails <= 3:
+                traceback.print_exc()
+        if fails >= 25:
+            break
+    print(f"fuzz: {n} cases, seed {seed}, big={big}: {fails} failures", flush=True)
+    return fails
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    sys.exit(1 if main(int(args[0]) if args else 2000, int(args[1]) if len(args) > 1 else 0, "--big" in sys.argv) else 0)
