@@ -1799,6 +1799,7 @@ def _basic_view(a: DeviceArray, entries):
 def _build_plan(a: DeviceArray, entries):
     """Index plan for a key with integer-array entries (NumPy advanced indexing
     rules: ints join the broadcast; separated index groups move to the front)."""
+    a.materialize()  # a pending (lazy) operand has no block yet
     adv_pos = [i for i, e in enumerate(entries) if e[0] in ("adv", "int")]
     idx_arrays = []
     for i in adv_pos:
