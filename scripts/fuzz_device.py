@@ -101,7 +101,8 @@ REDUCE = ["sum", "prod", "max", "min", "any", "all", "mean"]
 
 
 def one_case(rng, big):
-    kind = rng.choice(["unary", "binary", "where", "reduce", "arg", "gather", "scatter", "matmul", "astype"])
+    kind = rng.choice(["unary", "binary", "where", "reduce", "arg", "gather", "scatter", "matmul", "astype",
+                       "inplace", "concat", "along", "misc"])
     dt = DTYPES[int(rng.integers(0, len(DTYPES)))]
     shape = rand_shape(rng, big)
     h = rand_array(rng, shape, dt)
@@ -226,6 +227,77 @@ def one_case(rng, big):
             ref = a.astype(np.float64) @ b.astype(np.float64)
             tol = 3e-6 if fdt == np.float32 else 1e-13
             assert got.dtype == fdt and np.abs(got - ref).max() <= tol * (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)).max() + 1e-30, f"matmul {M}x{K}x{N} {fdt}"
+        elif kind == "inplace":
+            # views of one block written in place: the host copy must change the same way
+            h = np.array(h, order="C")
+            d = nd.asarray(h)
+            hv, dv = rand_view(rng, h, d)
+            k = rng.integers(0, 4)
+            other = rand_array(rng, broadcastable(rng, hv.shape), hv.dtype)
+            if hv.dtype.kind == "f":
+                other = np.nan_to_num(other, nan=1.0, posinf=2.0, neginf=-2.0).astype(hv.dtype)
+            if k == 0 and hv.dtype != np.bool_:
+                hv += other
+                dv += nd.asarray(other)
+            elif k == 1 and hv.dtype != np.bool_:
+                hv *= 2
+                dv *= 2
+            elif k == 2:
+                hv[...] = other
+                dv[...] = nd.asarray(other)
+            elif hv.ndim >= 1 and hv.shape[0] >= 2:
+                hv[1:] = hv[:-1].copy()
+                dv[1:] = nd.copy(dv[:-1])
+            close(d, h, f"inplace k={k} {hv.shape}{hv.dtype} strides={hv.strides}")
+        elif kind == "concat":
+            if h.ndim == 0:
+                return
+            ax = int(rng.integers(0, h.ndim))
+            parts_h, parts_d = [h], [d]
+            for _ in range(int(rng.integers(1, 3))):
+                sh = list(h.shape)
+                sh[ax] = int(rng.integers(0, 4))
+                p = rand_array(rng, tuple(sh), h.dtype)
+                parts_h.append(p)
+                parts_d.append(nd.asarray(p))
+            close(nd.concatenate(parts_d, axis=ax), np.concatenate(parts_h, axis=ax), f"concatenate {h.shape} ax={ax}")
+            sax = int(rng.integers(0, h.ndim + 1))
+            close(nd.stack([d, d], axis=sax), np.stack([h, h], axis=sax), f"stack {h.shape} ax={sax}")
+        elif kind == "along":
+            if h.ndim == 0 or h.size == 0 or h.dtype == np.bool_:
+                return
+            ax = int(rng.integers(0, h.ndim))
+            ish = list(h.shape)
+            ish[ax] = int(rng.integers(1, 4))
+            idx = rng.integers(0, h.shape[ax], tuple(ish))
+            close(nd.take_along_axis(d, nd.asarray(idx), axis=ax), np.take_along_axis(h, idx, axis=ax), f"take_along_axis {h.shape} ax={ax}")
+            am = np.argmax(np.nan_to_num(h), axis=ax, keepdims=True) if h.dtype.kind == "f" else np.argmax(h, axis=ax, keepdims=True)
+            hz = np.zeros(h.shape, dtype=h.dtype)
+            dz = nd.zeros(h.shape, dtype=h.dtype)
+            vals = rand_array(rng, am.shape, h.dtype)
+            np.put_along_axis(hz, am, vals, axis=ax)
+            nd.put_along_axis(dz, nd.asarray(am), nd.asarray(vals), axis=ax)
+            close(dz, hz, f"put_along_axis {h.shape} ax={ax}")
+        elif kind == "misc":
+            k = rng.integers(0, 5)
+            if k == 0 and h.ndim:
+                ax = None if rng.random() < 0.3 else int(rng.integers(0, h.ndim))
+                close(nd.flip(d, axis=ax), np.flip(h, axis=ax), f"flip {h.shape} ax={ax}")
+            elif k == 1:
+                reps = tuple(int(x) for x in rng.integers(1, 3, int(rng.integers(1, 4))))
+                close(nd.tile(d, reps), np.tile(h, reps), f"tile {h.shape} reps={reps}")
+            elif k == 2 and h.ndim:
+                ax = int(rng.integers(0, h.ndim))
+                close(nd.repeat(d, 2, axis=ax), np.repeat(h, 2, axis=ax), f"repeat {h.shape} ax={ax}")
+            elif k == 3 and h.dtype.kind == "f":
+                close(nd.clip(d, -0.5, 0.75), np.clip(h, -0.5, 0.75), f"clip {h.shape}")
+            elif k == 4 and h.dtype.kind == "f" and h.ndim and h.size:
+                hh = np.nan_to_num(h, nan=0.25, posinf=4.0, neginf=-4.0).astype(h.dtype)
+                ax = int(rng.integers(0, h.ndim))
+                got, exp = np.asarray(nd.std(nd.asarray(hh), axis=ax)), np.std(hh, axis=ax)
+                assert got.shape == exp.shape and got.dtype == exp.dtype
+                tol = 2e-5 if h.dtype == np.float32 else 1e-11
+                assert np.abs(got - exp).max() <= tol * (np.abs(hh).max() + 1.0), f"std {h.shape} ax={ax}"
         elif kind == "astype":
             to = DTYPES[int(rng.integers(0, len(DTYPES)))]
             if h.dtype.kind == "f" and np.dtype(to).kind in "iu":
