@@ -34,7 +34,10 @@ builtins_max = max
 def rand_shape(rng, big):
     nd_ = int(rng.integers(0, 5))
     if big and rng.random() < 0.5:
-        return tuple(int(x) for x in rng.choice([1, 2, 3, 17, 64, 130, 257, 1024], nd_ or 1))[:3]
+        shape = [int(x) for x in rng.choice([1, 2, 3, 17, 64, 130, 257, 1024], nd_ or 1)][:3]
+        while int(np.prod(shape)) > (1 << 22):       # bounded: <= 4M elements (32 MiB of f64) per operand
+            shape[int(np.argmax(shape))] //= 4
+        return tuple(shape)
     return tuple(int(x) for x in rng.integers(0 if rng.random() < 0.05 else 1, 9, nd_))
 
 
