@@ -290,14 +290,23 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch) {
     int v = atoi(e);
     if (v >= 0 && v < CFG_COUNT) return v;
   }
-  // Measured on MI355X (profiles/r1_gemm_tile_ab.log, random data, interleaved rounds):
-  // 256x128 wins whenever it still yields >= 2 blocks per CU (134 TF at 4096^3 and
-  // 8192x4096x4096); below that, smaller tiles keep >= 2 blocks per CU resident.
-  auto tiles = [&](int bm, int bn) { return ((ga.M + bm - 1) / bm) * ((ga.N + bn - 1) / bn) * batch; };
-  if (tiles(256, 128) >= 2 * MD_NUM_CUS) return CFG_256x128x16;
-  if (tiles(128, 128) >= 3 * MD_NUM_CUS) return CFG_128x128x16;
-  if (tiles(128, 64) >= 2 * MD_NUM_CUS) return CFG_128x64x16;
-  return CFG_64x64x16;
+  // Cost model over the four production tiles: a CU works through ceil(tiles / CUs) tiles of BM*BN
+  // outputs at the rate measured for that tile at 4096^3 (profiles/r1_gemm_tile_ab.log) — big tiles
+  // win on efficiency, small tiles on the partial last round of a grid that does not divide evenly
+  // (4097 rows: 3 rounds of 256x128 against 17 of 64x64, i.e. 0.80x the time).
+  struct Cand { int cfg, bm, bn; double tf; };
+  static const Cand cands[] = {{CFG_256x128x16, 256, 128, 136.0}, {CFG_128x128x16, 128, 128, 130.0},
+                               {CFG_128x64x16, 128, 64, 126.0}, {CFG_64x64x16, 64, 64, 120.0}};
+  int best = CFG_64x64x16;
+  double best_t = 1e300;
+  for (const Cand &c : cands) {
+    const int64_t tiles = ((ga.M + c.bm - 1) / c.bm) * ((ga.N + c.bn - 1) / c.bn) * batch;
+    const double rounds = (double)((tiles + MD_NUM_CUS - 1) / MD_NUM_CUS);
+    double t = rounds * c.bm * c.bn / c.tf;
+    if (tiles <= MD_NUM_CUS) t /= 0.8;  // a lone block per CU (one wave per SIMD) cannot keep the matrix pipe fed
+    if (t < best_t * 0.999) { best_t = t; best = c.cfg; }   // ties go to the larger tile (listed first)
+  }
+  return best;
 }
 
 template <bool A_KC, bool B_KC>
