@@ -282,8 +282,8 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
   return MD_LAUNCH_CHECK("matmul(f32 mfma)");
 }
 
-enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_128x128x32, CFG_256x128x16_8W, CFG_256x256x16_8W,
-       CFG_256x256x16_4W, CFG_COUNT };
+// (128x128x32, 8-wave 256x128 and 256x256 tiles were measured and dropped: profiles/r1_gemm_tile_ab.log)
+enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_COUNT };
 
 static int pick_cfg(const GemmArgs &ga, int64_t batch) {
   if (const char *e = getenv("MDHIP_GEMM_CFG")) {  // experiments only
@@ -315,10 +315,6 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
     case CFG_64x64x16: return launch_cfg<64, 64, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
     case CFG_128x64x16: return launch_cfg<128, 64, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
     case CFG_256x128x16: return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
-    case CFG_128x128x32: return launch_cfg<128, 128, 32, 2, 2, A_KC, B_KC>(ga, batch, edge);
-    case CFG_256x128x16_8W: return launch_cfg<256, 128, 16, 4, 2, A_KC, B_KC>(ga, batch, edge);
-    case CFG_256x256x16_8W: return launch_cfg<256, 256, 16, 4, 2, A_KC, B_KC>(ga, batch, edge);
-    case CFG_256x256x16_4W: return launch_cfg<256, 256, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
     default: return launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
   }
 }
