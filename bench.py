@@ -241,6 +241,14 @@ def main():
         if use_dist:
             dist.barrier()
 
+    # untimed pre-roll before the W warm-up sweeps: the first ~15 ms of work after process start run
+    # at ramping clocks and grow the allocator cache (W <= 2 alone measured 7 % low on cfg2)
+    # (a fixed count, not a time: every rank must issue the same number of collectives)
+    preroll = {"cfg2": 12, "cfg3": 20, "cfg4": 10, "cfg5": 40}[args.workload]
+    for _ in range(preroll):
+        sweep()
+    lib.sync()
+
     captured = None
     if args.graph:
         if use_dist:
@@ -367,6 +375,7 @@ def main():
         line = {
             "metric": "forward+backward passes/sec on 4096x4096 fp32 matmul+elementwise graph",
             "value": value, "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "preroll_sweeps": preroll,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": {
