@@ -2,7 +2,7 @@
 """Differential fuzzing of the device array library against NumPy: random shapes, dtypes, strided /
 transposed / broadcast views and argument forms for the elementwise, reduction, arg-reduction,
 indexing and matmul entry points. Integers / bools / indices must match bit for bit, floats within
-a few ulp-scaled tolerances.   python scripts/fuzz_device.py [n_cases] [seed] [--big]
+a few ulp-scaled tolerances.   python tests/fuzz_device.py [n_cases] [seed] [--big]
 Runs on whatever library the process binds (the GPU product by default; tests bind the CPU double)."""
 import os
 import sys

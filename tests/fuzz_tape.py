@@ -2,7 +2,7 @@
 """Differential fuzzing of forward+backward sweeps: a random expression graph over a few leaf
 tensors (elementwise ops with broadcasting, matmul, reductions, indexing, where/clip, second
 order) is run through the same tape on the device table and on the NumPy oracle table; outputs
-and every leaf gradient must agree.   python scripts/fuzz_tape.py [n_cases] [seed]"""
+and every leaf gradient must agree.   python tests/fuzz_tape.py [n_cases] [seed]"""
 import os
 import sys
 

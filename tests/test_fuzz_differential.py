@@ -1,4 +1,4 @@
-"""Differential fuzzing against NumPy (scripts/fuzz_device.py): random shapes, dtypes, strided /
+"""Differential fuzzing against NumPy (tests/fuzz_device.py): random shapes, dtypes, strided /
 transposed / broadcast views over the elementwise, reduction, arg-reduction, indexing, scatter and
 matmul entry points; ints / bools / indices bit for bit, floats within ulp-scaled bounds."""
 import os
@@ -6,7 +6,7 @@ import sys
 
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import fuzz_device  # noqa: E402
 
 
