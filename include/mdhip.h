@@ -148,6 +148,13 @@ int mdhip_mem_stats(int64_t stats[4]);
 int mdhip_h2d(void *dst, const void *src, size_t nbytes); /* async on stream for pinned src; ordered */
 int mdhip_d2h(void *dst, const void *src, size_t nbytes); /* SYNCHRONISES */
 int mdhip_d2d(void *dst, const void *src, size_t nbytes); /* async */
+/* Page-locked host blocks from a size-binned cache, for the host side of large transfers
+ * (as_numpy / array, numpy.py:174-185,204-206): a D2H copy into pageable, never-touched memory
+ * runs at the page-fault rate (2-11 GB/s measured), into a pinned block at the link rate. At most
+ * `MDHIP_PINNED_CAP` bytes (default 4 GiB) are outstanding; beyond that MDHIP_EMEMORY, and the
+ * caller uses ordinary memory. */
+int mdhip_host_alloc(size_t nbytes, void **ptr_out);
+int mdhip_host_free(void *ptr);
 int mdhip_sync(void);                                     /* stream + device */
 /* HIP events on the library's stream, for bench.py's per-kernel timing. */
 int mdhip_event_create(void **ev_out);

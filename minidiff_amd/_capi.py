@@ -94,6 +94,8 @@ _PROTOTYPES = {
     "mdhip_free": [C.c_void_p],
     "mdhip_empty_cache": [],
     "mdhip_mem_stats": [_P(C.c_int64)],
+    "mdhip_host_alloc": [C.c_size_t, _P(C.c_void_p)],
+    "mdhip_host_free": [C.c_void_p],
     "mdhip_h2d": [C.c_void_p, C.c_void_p, C.c_size_t],
     "mdhip_d2h": [C.c_void_p, C.c_void_p, C.c_size_t],
     "mdhip_d2d": [C.c_void_p, C.c_void_p, C.c_size_t],

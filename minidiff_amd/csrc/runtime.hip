@@ -186,6 +186,74 @@ int mdhip_mem_stats(int64_t st[4]) {
   return MDHIP_OK;
 }
 
+}  // extern "C"
+
+// ---- pinned host blocks (size-binned cache, bounded) ------------------------------------
+namespace {
+struct HostPool {
+  std::mutex mu;
+  std::map<size_t, std::vector<void *>> free_lists;
+  std::unordered_map<void *, size_t> live;
+  int64_t outstanding = 0, cached = 0;
+};
+HostPool &HP() {
+  static HostPool h;
+  return h;
+}
+int64_t pinned_cap() {
+  static int64_t v = [] {
+    const char *e = getenv("MDHIP_PINNED_CAP");
+    return e ? (int64_t)atoll(e) : ((int64_t)4 << 30);
+  }();
+  return v;
+}
+}  // namespace
+
+extern "C" {
+
+int mdhip_host_alloc(size_t nbytes, void **ptr_out) {
+  if (!S().stream) return md_fail(MDHIP_ERUNTIME, "mdhip_init has not been called");
+  const size_t r = round_size(nbytes);
+  HostPool &h = HP();
+  std::lock_guard<std::mutex> lk(h.mu);
+  if (h.outstanding + (int64_t)r > pinned_cap()) return md_fail(MDHIP_EMEMORY, "pinned host memory cap reached");
+  void *p = nullptr;
+  auto it = h.free_lists.find(r);
+  if (it != h.free_lists.end() && !it->second.empty()) {
+    p = it->second.back();
+    it->second.pop_back();
+    h.cached -= (int64_t)r;
+  } else {
+    if (h.cached + h.outstanding + (int64_t)r > pinned_cap()) {  // make room: drop the cache
+      for (auto &kv : h.free_lists)
+        for (void *q : kv.second) (void)hipHostFree(q);
+      h.free_lists.clear();
+      h.cached = 0;
+    }
+    if (hipHostMalloc(&p, r, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return md_fail(MDHIP_EMEMORY, "Unable to pin %zu bytes of host memory", nbytes);
+    }
+  }
+  h.live[p] = r;
+  h.outstanding += (int64_t)r;
+  *ptr_out = p;
+  return MDHIP_OK;
+}
+int mdhip_host_free(void *p) {
+  if (!p) return MDHIP_OK;
+  HostPool &h = HP();
+  std::lock_guard<std::mutex> lk(h.mu);
+  auto it = h.live.find(p);
+  if (it == h.live.end()) return md_fail(MDHIP_EVALUE, "free of unknown pinned pointer %p", p);
+  const size_t r = it->second;
+  h.live.erase(it);
+  h.outstanding -= (int64_t)r;
+  h.free_lists[r].push_back(p);
+  h.cached += (int64_t)r;
+  return MDHIP_OK;
+}
+
 int mdhip_h2d(void *dst, const void *src, size_t n) {
   if (!n) return MDHIP_OK;
   MD_TRY(md_hip_check(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, md_stream()), "hipMemcpyAsync(H2D)"));

@@ -102,6 +102,36 @@ class _Buffer:
             pass
 
 
+_PINNED_MIN = 1 << 20
+
+
+class _PinnedOwner:
+    """Returns a pinned host block to the pool when the ctypes view (hence every ndarray over it) is gone."""
+
+    __slots__ = ("ptr", "_free")
+
+    def __init__(self, ptr, free):
+        self.ptr, self._free = ptr, free
+
+    def __del__(self):
+        try:
+            self._free(C.c_void_p(self.ptr))
+        except Exception:  # interpreter teardown
+            pass
+
+
+def _pinned_empty(shape, dtype, nbytes):
+    lib = _lib()
+    p = C.c_void_p()
+    try:
+        lib.host_alloc(nbytes, C.byref(p))
+    except MemoryError:
+        return None
+    view = (C.c_char * nbytes).from_address(p.value)
+    view._owner = _PinnedOwner(p.value, lib.cdll.mdhip_host_free)
+    return np.frombuffer(view, dtype=dtype).reshape(shape)
+
+
 def _c_strides(shape) -> tuple:
     st = [0] * len(shape)
     acc = 1
@@ -319,11 +349,18 @@ class DeviceArray:
 
     # ---- host transfer ------------------------------------------------------
     def get(self) -> np.ndarray:
-        """D2H copy (synchronises the stream)."""
+        """D2H copy (synchronises the stream). Large results land in a page-locked block from
+        libmdhip's host pool (returned to the pool when the last NumPy view of it dies): a copy into
+        fresh pageable memory runs at the page-fault rate, not the link rate."""
         src = self if self.is_c_contiguous else copy(self)
-        host = np.empty(self.shape, dtype=self.dtype)
-        if host.nbytes:
-            _lib().d2h(host.ctypes.data, src.ptr, host.nbytes)
+        nbytes = src.size * self.dtype.itemsize
+        host = None
+        if nbytes >= _PINNED_MIN:
+            host = _pinned_empty(self.shape, self.dtype, nbytes)
+        if host is None:
+            host = np.empty(self.shape, dtype=self.dtype)
+        if nbytes:
+            _lib().d2h(host.ctypes.data, src.ptr, nbytes)
         return host
 
     def __array__(self, dtype=None, copy=None):

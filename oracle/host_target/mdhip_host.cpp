@@ -160,6 +160,8 @@ int mdhip_mem_stats(int64_t s[4]) {
   s[0] = g_in_use; s[1] = 0; s[2] = g_peak; s[3] = g_nalloc;
   return MDHIP_OK;
 }
+int mdhip_host_alloc(size_t n, void **p) { *p = malloc(n ? n : 1); return *p ? MDHIP_OK : md_fail(MDHIP_EMEMORY, "host_alloc failed"); }
+int mdhip_host_free(void *p) { free(p); return MDHIP_OK; }
 int mdhip_h2d(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return MDHIP_OK; }
 int mdhip_d2h(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return MDHIP_OK; }
 int mdhip_d2d(void *d, const void *s, size_t n) { if (n) memmove(d, s, n); return MDHIP_OK; }
