@@ -785,8 +785,9 @@ def _straighten(x):
     would be read one element per cache line by the generic kernel; the tiled transposing copy
     runs ~3x faster than that, and the streaming kernel then takes the contiguous copy."""
     st = x._strides
-    if x.size >= (1 << 16) and len(st) >= 2 and x._expr is None and st[-1] not in (0, 1) and 1 in st[-3:-1] \
-            and x.shape[-1] >= 32:
+    if len(st) < 2 or st[-1] == 1 or st[-1] == 0:   # the common case first: this runs on every binary call
+        return x
+    if x.size >= (1 << 16) and x._expr is None and 1 in st[-3:-1] and x.shape[-1] >= 32:
         return copy(x)
     return x
 
