@@ -329,7 +329,7 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
 // and up) and any f64 user; the fp32 headline never comes here.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
-constexpr int LDP64 = 16;  // LDS row pad (doubles): the two 16-lane k-groups of a half-wave land on disjoint banks
+constexpr int LDP64 = 18;  // LDS row pad (doubles): transposing b64 stores of a half-wave hit 64 distinct banks; fragment reads overlap by 2 lanes
 
 struct GemmArgs64 {
   const double *A, *B;
