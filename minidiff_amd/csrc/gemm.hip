@@ -102,7 +102,10 @@ __device__ __forceinline__ void store_tile(float (*S)[ROWS + LDP], const f32x4 (
 }
 
 // BM x BN block tile, BK k-step, WM x WN waves, each wave (WTM*32) x (WTN*32).
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool EDGE>
+// SPLITK is a separate instantiation on purpose: with the k-range arithmetic compiled into the plain
+// kernel its main loop came out instruction-for-instruction the same but with another register
+// assignment, and NN at 4096^3 dropped from 136.6 to 133.3 TFLOP/s (same-box A/B).
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool EDGE, bool SPLITK = false>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_mfma(GemmArgs g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);  // MFMA tiles per wave along m / n
@@ -116,11 +119,17 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_mfma(GemmArgs g) {
   const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const int64_t bz = blockIdx.z;
-  const int64_t ks0 = (int64_t)blockIdx.y * g.k_chunk;
-  const float *A = g.A + bz * g.a_bs + ks0 * g.a_ks;
-  const float *B = g.B + bz * g.b_bs + ks0 * g.b_ks;
-  float *C = g.C + bz * g.c_bs + (int64_t)blockIdx.y * g.c_split;
-  const int64_t Kl = (gridDim.y > 1 && g.K - ks0 > g.k_chunk) ? g.k_chunk : g.K - ks0;  // this block's k extent
+  const float *A = g.A + bz * g.a_bs;
+  const float *B = g.B + bz * g.b_bs;
+  float *C = g.C + bz * g.c_bs;
+  int64_t Kl = g.K;  // this block's k extent
+  if constexpr (SPLITK) {
+    const int64_t ks0 = (int64_t)blockIdx.y * g.k_chunk;
+    A += ks0 * g.a_ks;
+    B += ks0 * g.b_ks;
+    C += (int64_t)blockIdx.y * g.c_split;
+    Kl = g.K - ks0 > g.k_chunk ? g.k_chunk : g.K - ks0;
+  }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -251,7 +260,7 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
   const int64_t tiles = (int64_t)ga.tiles_m * ga.tiles_n * batch;
   int64_t splits = 1;
   static const int splitk_mode = [] { const char *e = getenv("MDHIP_GEMM_SPLITK"); return e ? atoi(e) : 1; }();
-  if (splitk_mode && tiles < MD_NUM_CUS && ga.K >= 1024) {
+  if (splitk_mode && BM == 64 && BN == 64 && tiles < MD_NUM_CUS && ga.K >= 1024) {  // (pick_cfg sends such shapes to 64x64)
     splits = (2 * MD_NUM_CUS + tiles - 1) / tiles;
     if (splits > ga.K / 512) splits = ga.K / 512;
     if (splits > 64) splits = 64;
@@ -270,8 +279,16 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
     edge = edge || (ga.k_chunk % BK) || (ga.K % ga.k_chunk % BK);
   }
   dim3 grid((unsigned)(ga.tiles_m * ga.tiles_n), (unsigned)splits, (unsigned)batch);
-  if (edge) k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, true><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
-  else k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, false><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
+  if constexpr (BM == 64 && BN == 64) {
+    if (splits > 1) {
+      if (edge) k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, true, true><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
+      else k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, false, true><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
+    }
+  }
+  if (splits == 1) {
+    if (edge) k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, true><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
+    else k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, false><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
+  }
   if (splits > 1) {
     k_gemm_splitk_sum<<<md_grid_for(batch * ga.M * ga.N), MD_BLOCK, 0, md_stream()>>>((const float *)partial, (int)splits, batch, ga.M, ga.N,
                                                                                    out.C, out.c_bs, out.c_ms, out.c_ns);
@@ -294,6 +311,7 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch) {
   // outputs at the rate measured for that tile at 4096^3 (profiles/r1_gemm_tile_ab.log) — big tiles
   // win on efficiency, small tiles on the partial last round of a grid that does not divide evenly
   // (4097 rows: 3 rounds of 256x128 against 17 of 64x64, i.e. 0.80x the time).
+  if (((ga.M + 63) / 64) * ((ga.N + 63) / 64) * batch < MD_NUM_CUS && ga.K >= 1024) return CFG_64x64x16;  // split-K candidates
   struct Cand { int cfg, bm, bn; double tf; };
   static const Cand cands[] = {{CFG_256x128x16, 256, 128, 136.0}, {CFG_128x128x16, 128, 128, 130.0},
                                {CFG_128x64x16, 128, 64, 126.0}, {CFG_64x64x16, 64, 64, 120.0}};

@@ -35,7 +35,8 @@ def main():
         for rnd in range(3):
             for cfg in CFGS:
                 os.environ["MDHIP_GEMM_CFG"] = str(cfg)
-                for tag, a, b in (("NN", A, B), ("NT", A, Bt.T), ("TN", At.T, B)):
+                combos = (("NN", A, B), ("NT", A, Bt.T), ("TN", At.T, B)) + ((("TT", At.T, Bt.T),) if os.environ.get("GEMM_TT") else ())
+                for tag, a, b in combos:
                     nd.matmul(a, b)  # warm
                     lib.event_record(e0)
                     for _ in range(5):
@@ -51,7 +52,7 @@ def main():
                         assert np.abs(h - ref).max() / np.abs(ref).max() < 2e-6, (cfg, tag)
         print(f"M={M} K={K} N={N}")
         for cfg, name in CFGS.items():
-            print("   %-11s " % name + "  ".join("%s med %6.1f max %6.1f TF" % (t, sorted(res[(cfg, t)])[1], max(res[(cfg, t)])) for t in ("NN", "NT", "TN")))
+            print("   %-11s " % name + "  ".join("%s med %6.1f max %6.1f TF" % (t, sorted(res[(cfg, t)])[1], max(res[(cfg, t)])) for t in (("NN", "NT", "TN", "TT") if os.environ.get("GEMM_TT") else ("NN", "NT", "TN"))))
     del os.environ["MDHIP_GEMM_CFG"]
 
 
