@@ -156,8 +156,13 @@ class Library:
         self.target = self.cdll.mdhip_target().decode()
         self._initialised = False
         # bind hot entry points once (attribute lookups on CDLL are slow)
+        trace = os.environ.get("MDHIP_TRACE")
+        self._trace_file = open(trace, "a", buffering=1) if trace else None
         for name in _PROTOTYPES:
-            setattr(self, name[len("mdhip_"):], self._checked(getattr(self.cdll, name)))
+            fn = self._checked(getattr(self.cdll, name))
+            if self._trace_file is not None:
+                fn = self._traced(fn, name[len("mdhip_"):])
+            setattr(self, name[len("mdhip_"):], fn)
 
     def _checked(self, fn):
         last_error = self.cdll.mdhip_last_error
@@ -168,6 +173,33 @@ class Library:
                 raise _EXC.get(st, RuntimeError)(last_error().decode(errors="replace"))
 
         call.__name__ = fn.__name__
+        return call
+
+    def _traced(self, fn, name):
+        """MDHIP_TRACE=<file>: one JSON line per C-ABI call — entry point, host-side duration, and for
+        array arguments dtype code / shape / element strides (SURVEY.md §5 "call log at the C-ABI shim").
+        Kernels are asynchronous: the duration is enqueue time, not execution time (use rocprofv3 for that)."""
+        import json
+        import time
+
+        out = self._trace_file
+
+        def call(*args):
+            t0 = time.perf_counter()
+            try:
+                return fn(*args)
+            finally:
+                rec = {"call": name, "us": round((time.perf_counter() - t0) * 1e6, 1), "args": []}
+                for a in args:
+                    a = getattr(a, "_obj", a)  # byref(...) wrapper
+                    if isinstance(a, ArrayDesc):
+                        nd = a.ndim
+                        rec["args"].append({"dtype": a.dtype, "shape": list(a.shape[:nd]), "strides": list(a.strides[:nd]),
+                                            "scalar": bool(a.is_scalar)})
+                    elif isinstance(a, (int, float)):
+                        rec["args"].append(a)
+                out.write(json.dumps(rec) + "\n")
+
         return call
 
     def ensure_init(self, device: int | None = None):
