@@ -759,6 +759,11 @@ def _binary(ufunc, code, a, b, out=None):
         a = _straighten(a)
     if b_arr:
         b = _straighten(b)
+    if out is not None:
+        if a_arr:
+            a = _unalias(a, out)
+        if b_arr:
+            b = _unalias(b, out)
     da = _operand_desc(a, shape, 0 if a_arr else _scalar_code(a, cdt))
     db = _operand_desc(b, shape, 0 if b_arr else _scalar_code(b, cdt))
     if out is None:
@@ -822,10 +827,37 @@ def _unary(ufunc, code, x):
     return res
 
 
+def _extent(a: "DeviceArray"):
+    """[lo, hi] element range of the block that the view touches."""
+    lo = hi = a._offset
+    for n, st in zip(a.shape, a._strides):
+        if n > 1:
+            if st > 0:
+                hi += (n - 1) * st
+            else:
+                lo += (n - 1) * st
+    return lo, hi
+
+
+def _unalias(x, out: "DeviceArray"):
+    """NumPy's ufunc machinery gives in-place calls whose operand OVERLAPS the destination the result of
+    operating on a copy (`a[1:] += a[:-1]`, `a += a.T`); a kernel that reads and writes the same
+    block concurrently would not. The identical view (`a += a`, `a *= a`) is safe element by element."""
+    if not isinstance(x, DeviceArray) or x._buf is None or x._buf is not out._buf or x.size == 0:
+        return x
+    if x._offset == out._offset and x.shape == out.shape and x._strides == out._strides:
+        return x
+    (xl, xh), (ol, oh) = _extent(x), _extent(out)
+    if xh < ol or oh < xl:
+        return x
+    return copy(x)
+
+
 def _copy_into(dst: DeviceArray, src, shape=None):
     """dst[...] = src with broadcasting and dtype conversion (unary COPY kernel)."""
     _before_write(dst)
     if isinstance(src, DeviceArray):
+        src = _unalias(src, dst)
         sd = src.desc(dst.shape)
     else:
         src = _operand(src)

@@ -249,8 +249,16 @@ def one_case(rng, big):
                 hv[...] = other
                 dv[...] = nd.asarray(other)
             elif hv.ndim >= 1 and hv.shape[0] >= 2:
-                hv[1:] = hv[:-1].copy()
-                dv[1:] = nd.copy(dv[:-1])
+                # operand overlapping the destination: NumPy computes as if from a copy
+                if hv.dtype != np.bool_ and rng.random() < 0.5:
+                    hv[1:] += hv[:-1]
+                    dv[1:] += dv[:-1]
+                else:
+                    hv[1:] = hv[:-1]
+                    dv[1:] = dv[:-1]
+            if hv.ndim == 2 and hv.shape[0] == hv.shape[1] and hv.dtype != np.bool_ and rng.random() < 0.5:
+                hv += hv.T
+                dv += dv.T
             close(d, h, f"inplace k={k} {hv.shape}{hv.dtype} strides={hv.strides}")
         elif kind == "concat":
             if h.ndim == 0:

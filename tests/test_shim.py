@@ -69,3 +69,41 @@ def test_case_cpu(lib, on_gpu, case): _run(lib, on_gpu, False, getattr(cs, case)
 @gpu
 @pytest.mark.parametrize("case", SINGLE)
 def test_case_gpu(lib, on_gpu, case): _run(lib, on_gpu, True, getattr(cs, case))
+
+
+def _overlap_case(nd_unused):
+    """`a[1:] += a[:-1]`, `a[1:] = a[:-1]`, `a += a.T`, `a[::-1] += a`: NumPy gives the result of
+    operating on a copy of the overlapping operand (tensor.py:269-362 hands raw arrays to these)."""
+    import numpy as np
+    from minidiff_amd import ndarray as nd
+    for dt in (np.float64, np.float32, np.int64):
+        h = np.arange(40, dtype=dt)
+        d = nd.asarray(h)
+        h[1:] += h[:-1]
+        d[1:] += d[:-1]
+        assert np.array_equal(np.asarray(d), h)
+        h[1:] = h[:-1]
+        d[1:] = d[:-1]
+        assert np.array_equal(np.asarray(d), h)
+        h[::-1] += h
+        d[::-1] += d
+        assert np.array_equal(np.asarray(d), h)
+        h2 = np.arange(36, dtype=dt).reshape(6, 6)
+        d2 = nd.asarray(h2)
+        h2 += h2.T
+        d2 += d2.T
+        assert np.array_equal(np.asarray(d2), h2)
+        h2 *= h2
+        d2 *= d2                       # the identical view: no copy needed, same answer
+        assert np.array_equal(np.asarray(d2), h2)
+        h2[:, 1:] -= h2[:, :-1]
+        d2[:, 1:] -= d2[:, :-1]
+        assert np.array_equal(np.asarray(d2), h2)
+        h2[::2] = h2[1::2]             # interleaved rows: disjoint, but ranges intersect (copied, still right)
+        d2[::2] = d2[1::2]
+        assert np.array_equal(np.asarray(d2), h2)
+
+
+def test_inplace_overlap_cpu(lib, on_gpu): _run(lib, on_gpu, False, _overlap_case)
+@gpu
+def test_inplace_overlap_gpu(lib, on_gpu): _run(lib, on_gpu, True, _overlap_case)
