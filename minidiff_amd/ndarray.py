@@ -939,6 +939,8 @@ logical_xor = _mk_binary(np.logical_xor, _capi.B_LXOR)
 
 
 def where(condition, x=None, y=None):
+    if x is None and y is None:
+        return nonzero(condition)   # np.where(cond) is np.nonzero(cond)
     if x is None or y is None:
         raise ValueError("either both or neither of x and y should be given")
     c, a, b = _operand(condition), _operand(x), _operand(y)
