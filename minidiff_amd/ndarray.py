@@ -468,6 +468,12 @@ class DeviceArray:
 
     def argmax(self, axis=None, out=None, keepdims=False):
         return argmax(self, axis=axis, keepdims=keepdims)
+    def clip(self, a_min=None, a_max=None, **kw): return clip(self, a_min, a_max, **kw)
+    def std(self, axis=None, dtype=None, out=None, ddof=0, keepdims=False): return std(self, axis=axis, dtype=dtype, ddof=ddof, keepdims=keepdims)
+    def swapaxes(self, a0, a1): return swapaxes(self, a0, a1)
+    def nonzero(self): return nonzero(self)
+    def repeat(self, repeats, axis=None): return repeat(self, repeats, axis=axis)
+
 
     def argmin(self, axis=None, out=None, keepdims=False):
         return argmin(self, axis=axis, keepdims=keepdims)
