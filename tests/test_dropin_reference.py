@@ -20,3 +20,39 @@ def test_reference_runs_on_plugin_backend(lib, on_gpu):
                        timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "DROPIN-OK" in p.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "minidiff")), reason="reference checkout not present")
+def test_reference_fuzz_numpy_backend_vs_plugin(lib, on_gpu, tmp_path):
+    """300 random forward+backward programs (tests/fuzz_tape.py) through the real reference's own tape:
+    its NumPy backend and the plug-in must agree on every output, gradient and raised exception type."""
+    if on_gpu:
+        pytest.skip("runs against the CPU test double")
+    import pickle
+
+    import numpy as np
+    sys.path.insert(0, HERE)
+    import fuzz_tape
+    outs = {}
+    for which in ("numpy", "plugin"):
+        path = tmp_path / f"{which}.pkl"
+        p = subprocess.run([sys.executable, os.path.join(HERE, "dropin_fuzz_script.py"), which, "300", "7", str(path)],
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        outs[which] = pickle.loads(path.read_bytes())
+    assert len(outs["numpy"]) == len(outs["plugin"]) == 300
+    n_ok = 0
+    for i, (a, b) in enumerate(zip(outs["numpy"], outs["plugin"])):
+        assert a[0] == b[0], (i, a[:2], b[:2])
+        if a[0] == "raise":
+            assert a[1] == b[1], (i, a, b)
+            continue
+        n_ok += 1
+        dt = np.dtype(a[5]).type
+        fuzz_tape.close(b[1], a[1], dt, f"case {i} output")
+        for k, (ga, gb) in enumerate(zip(a[3], b[3])):
+            fuzz_tape.close(gb, ga, dt, f"case {i} grad[{k}]")
+        if a[4] is not None:
+            for k, (ga, gb) in enumerate(zip(a[4], b[4])):
+                fuzz_tape.close(gb, ga, dt, f"case {i} second-order grad[{k}]")
+    assert n_ok > 150
