@@ -34,15 +34,20 @@ def test_reference_fuzz_numpy_backend_vs_plugin(lib, on_gpu, tmp_path):
     sys.path.insert(0, HERE)
     import fuzz_tape
     outs = {}
-    for which in ("numpy", "plugin"):
+    for which, env in (("numpy", {}), ("plugin", {"MDHIP_LAZY": "0"}), ("plugin-lazy", {"MDHIP_LAZY": "1"})):
         path = tmp_path / f"{which}.pkl"
-        p = subprocess.run([sys.executable, os.path.join(HERE, "dropin_fuzz_script.py"), which, "300", "7", str(path)],
-                           capture_output=True, text=True, timeout=900)
+        p = subprocess.run([sys.executable, os.path.join(HERE, "dropin_fuzz_script.py"), which.split("-")[0], "300", "7", str(path)],
+                           capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
         outs[which] = pickle.loads(path.read_bytes())
-    assert len(outs["numpy"]) == len(outs["plugin"]) == 300
+    assert len(outs["numpy"]) == len(outs["plugin"]) == len(outs["plugin-lazy"]) == 300
+    for mode in ("plugin", "plugin-lazy"):   # the fused-chain layer sits under the same unmodified tape
+        _compare(outs["numpy"], outs[mode], fuzz_tape, np)
+
+
+def _compare(ref, got, fuzz_tape, np):
     n_ok = 0
-    for i, (a, b) in enumerate(zip(outs["numpy"], outs["plugin"])):
+    for i, (a, b) in enumerate(zip(ref, got)):
         assert a[0] == b[0], (i, a[:2], b[:2])
         if a[0] == "raise":
             assert a[1] == b[1], (i, a, b)
