@@ -96,3 +96,36 @@ def test_matmul_properties_4096(lib, on_gpu):
     rows = rng.integers(0, n, 6)
     ref = Ah[rows].astype(np.float64) @ Bh.astype(np.float64)
     assert _rel(Ch[rows], ref) < 1e-5  # fp32 fma chain of length 4096 vs float64: ~3e-6 (north_star bound 1e-5)
+
+
+@pytest.mark.gpu
+def test_more_than_2_to_31_elements_gpu(lib, on_gpu):
+    """64-bit indexing end to end: fills, streaming kernels, reductions, arg-reductions, views, gathers and
+    scatters on arrays with more than 2**31 elements (8.6 GB of float32; the card has 288 GB)."""
+    assert on_gpu
+    import numpy as np
+    from minidiff_amd import ndarray as nd
+    n = (1 << 31) + 4099
+    b = nd.ones((n,), dtype=np.bool_)
+    assert int(np.asarray(nd.sum(b))) == n                      # int64 accumulation: exact
+    x = nd.full((n,), 0.5, dtype=np.float32)
+    mark = (1 << 31) + 7
+    x[mark:mark + 1] = 3.0
+    x[5:6] = -2.0
+    y = nd.add(nd.multiply(x, 2.0), 1.0)                        # two streaming kernels over 8.6 GB each way
+    assert float(np.asarray(y[mark])) == 7.0 and float(np.asarray(y[n - 1])) == 2.0 and float(np.asarray(y[5])) == -3.0
+    assert int(np.asarray(nd.argmax(y))) == mark and int(np.asarray(nd.argmin(y))) == 5
+    assert float(np.asarray(nd.max(y))) == 7.0
+    s = float(np.asarray(nd.sum(y, dtype=np.float64)))
+    assert s == 2.0 * (n - 2) + 7.0 - 3.0
+    tail = y[(1 << 31):]                                        # a view starting beyond 2**31
+    assert tail.shape == (4099,) and float(np.asarray(tail[7])) == 7.0
+    idx = nd.asarray(np.array([5, mark, n - 1, 0], dtype=np.int64))
+    assert np.array_equal(np.asarray(y[idx]), np.array([-3.0, 7.0, 2.0, 2.0], dtype=np.float32))
+    nd.index_add(y, idx, nd.asarray(np.array([1.0, 1.0, 1.0, 1.0], dtype=np.float32)))
+    assert np.array_equal(np.asarray(y[idx]), np.array([-2.0, 8.0, 3.0, 3.0], dtype=np.float32))
+    m = nd.reshape(y[: 4096 * 524289], (524289, 4096))          # 2-D, 2**31 + 4096 elements
+    col = np.asarray(nd.sum(m, axis=0, dtype=np.float64))
+    assert col.shape == (4096,) and col[1] == 2.0 * 524289 and col[7] == 2.0 * 524288 + 8.0
+    row = np.asarray(nd.sum(m, axis=1, dtype=np.float64))
+    assert row.shape == (524289,) and row[1] == 2.0 * 4096 and row[524288] == 2.0 * 4095 + 8.0
