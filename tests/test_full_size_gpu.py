@@ -129,3 +129,24 @@ def test_more_than_2_to_31_elements_gpu(lib, on_gpu):
     assert col.shape == (4096,) and col[1] == 2.0 * 524289 and col[7] == 2.0 * 524288 + 8.0
     row = np.asarray(nd.sum(m, axis=1, dtype=np.float64))
     assert row.shape == (524289,) and row[1] == 2.0 * 4096 and row[524288] == 2.0 * 4095 + 8.0
+
+
+@pytest.mark.gpu
+def test_matmul_with_more_than_2_to_31_outputs_gpu(lib, on_gpu):
+    assert on_gpu
+    import numpy as np
+    from minidiff_amd import ndarray as nd
+    rng = np.random.default_rng(12)
+    M, K, N = 65536, 64, 32800                     # 2.15e9 outputs (8.6 GB of float32)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    b = rng.standard_normal((K, N)).astype(np.float32)
+    c = nd.matmul(nd.asarray(a), nd.asarray(b))
+    assert c.shape == (M, N)
+    rows = np.array([0, 1, 32767, 32768, 65535])
+    got = np.asarray(c[nd.asarray(rows)])
+    ref = a[rows].astype(np.float64) @ b.astype(np.float64)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
+    cols = np.array([0, 31, 32799])
+    got = np.asarray(c[:, nd.asarray(cols)])
+    ref = a.astype(np.float64) @ b[:, cols].astype(np.float64)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
