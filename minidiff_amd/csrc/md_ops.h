@@ -370,9 +370,14 @@ template <class T> MD_HD T md_highest() {
   else if constexpr (sizeof(T) == 4) return (T)INT32_MAX;
   else return (T)1;
 }
+// (device, float: IEEE-754 maximum/minimum — one v_maximum3_f32 / v_minimum3_f32 on gfx950 instead of
+// two NaN tests and a select; the reductions were VALU-limited on it)
 struct RMax {  // NaN-propagating like np.max
   template <class T> static MD_HD T identity() { return md_lowest<T>(); }
   template <class T> static MD_HD T combine(T a, T b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (md_same<T, float>::value) return __builtin_elementwise_maximum(a, b);
+#endif
     if constexpr (md_is_float<T>::value) {
       if (a != a) return a;
       if (b != b) return b;
@@ -383,6 +388,9 @@ struct RMax {  // NaN-propagating like np.max
 struct RMin {
   template <class T> static MD_HD T identity() { return md_highest<T>(); }
   template <class T> static MD_HD T combine(T a, T b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (md_same<T, float>::value) return __builtin_elementwise_minimum(a, b);
+#endif
     if constexpr (md_is_float<T>::value) {
       if (a != a) return a;
       if (b != b) return b;

@@ -492,8 +492,9 @@ struct HipExec {
         static const int sweep_mode = [] { const char *e = getenv("MDHIP_COLS_SWEEP"); return e ? atoi(e) : 1; }();
         const int64_t qv = n_out / (MD_BLOCK * V);
         // (one long block per CU measured best: 4.9 TB/s at 8192 x 4096 f32 against 4.0 with two and 3.8 for the
-        // tiled kernel below; max/min keep the tiled kernel — their NaN-aware combine wants more waves per CU)
-        constexpr bool cheap = md_same<R, RSum>::value || md_same<R, RProd>::value;
+        // tiled kernel below; f64 / integer max and min keep the tiled kernel — their compare chain wants more waves per CU)
+        constexpr bool cheap = md_same<R, RSum>::value || md_same<R, RProd>::value ||
+                               ((md_same<R, RMax>::value || md_same<R, RMin>::value) && md_same<Tacc, float>::value);
         if (cheap && vec_ok && sweep_mode && n_out == qv * MD_BLOCK * V && (qv == 1 || qv == 2 || qv == 4 || qv == 8) && n_red >= 512) {
           int64_t nblk = sweep_mode > 1 ? sweep_mode : MD_NUM_CUS;
           if (nblk > n_red / 6) nblk = n_red / 6;
