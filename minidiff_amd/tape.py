@@ -95,6 +95,7 @@ def build_engine(B, name: str = "engine"):
         return t
 
     E.try_unwrap = try_unwrap
+    _PLAIN = (int, float, bool, type(None))
 
     # ----------------------------------------------------------------- node ----
     class Node:
@@ -386,7 +387,9 @@ def build_engine(B, name: str = "engine"):
         """backend function -> Tensor function (unwrap, call, wrap)."""
         def lifted(*args, **kwargs):
             allow = _wants_grad(args)
-            out = fn(*try_unwrap(args), **try_unwrap(kwargs))
+            # (the common call — Tensors and scalars, no keyword arguments — without the generic recursion)
+            raw = [a._data if type(a) is Tensor else (a if type(a) in _PLAIN else try_unwrap(a)) for a in args]
+            out = fn(*raw, **try_unwrap(kwargs)) if kwargs else fn(*raw)
             return Tensor(out, allow_grad=allow)
         lifted.__name__ = getattr(fn, "__name__", "backend_fn")
         return lifted
