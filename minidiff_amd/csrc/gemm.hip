@@ -9,14 +9,19 @@
 //
 // f32: v_mfma_f32_32x32x2_f32 — exact f32 fma chain in k order, 256 FLOP/clk/CU
 // (MI355X_MICROARCH.md "Matrix cores"): bound = 157.3 TFLOP/s.
-//   block tile BM x BN x BK (128x128x16 by default; smaller tiles when the problem
-//   would otherwise leave CUs with <3 resident blocks), 4 waves (2x2), each wave
-//   (BM/2)x(BN/2) in 32x32 MFMA tiles (64 accumulator VGPRs at 128x128). Operands are staged in LDS k-major ([k][m], [k][n])
+//   block tile BM x BN x BK (256x128x16 for large problems; a cost model picks smaller tiles
+//   for grids that do not fill whole rounds), 4 waves (2x2), each wave (BM/2)x(BN/2) in 32x32
+//   MFMA tiles (128 accumulator VGPRs at 256x128). Operands are staged in LDS k-major ([k][m], [k][n])
 //   so a fragment read is one conflict-free ds_read_b32 per MFMA operand. Three
 //   tiles are in flight per block: LDS buffer `cur` (being multiplied), the other
 //   LDS buffer (being written from registers during the first MFMA steps) and the
 //   registers (global loads of tile k+2 issued in step 2); fragment reads run one
-//   step ahead in a register double buffer; one barrier per k-step.
+//   step ahead in a register double buffer; one barrier per k-step. The k-tile body is
+//   branch-free (one scheduling region) and sched_group_barrier places a slice of the step's
+//   LDS reads / LDS writes / global loads behind EVERY MFMA, so a wave keeps the matrix pipe
+//   fed while its memory work issues in the gaps (136 -> 139.5 TFLOP/s at 4096^3; with one
+//   block per CU 60 -> 66). The loop is rotated: a tile's first fragments are read right
+//   behind the barrier that publishes it, under the previous step's MFMAs.
 //   Workgroup ids are remapped so the 8 XCDs each own a contiguous band of
 //   output tiles (per-XCD L2 locality on the shared A row panel).
 // ragged or unaligned shapes: guarded edge variant of the same kernel; few tiles and a long k:
@@ -105,7 +110,7 @@ __device__ __forceinline__ void store_tile(float (*S)[ROWS + LDP], const f32x4 (
 // SPLITK is a separate instantiation on purpose: with the k-range arithmetic compiled into the plain
 // kernel its main loop came out instruction-for-instruction the same but with another register
 // assignment, and NN at 4096^3 dropped from 136.6 to 133.3 TFLOP/s (same-box A/B).
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool EDGE, bool SPLITK = false>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool EDGE, bool SPLITK = false, int SCHED = 0>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_mfma(GemmArgs g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);  // MFMA tiles per wave along m / n
@@ -162,13 +167,21 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_mfma(GemmArgs g) {
   __syncthreads();
 
   int cur = 0;
+  float fa[2][WTM], fb[2][WTN];
+  if constexpr (SCHED != 0) {  // rotated loop: a tile's first fragments are read right behind the barrier that publishes it
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) fa[0][i] = As[0][h][wm * (WTM * 32) + i * 32 + l32];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) fb[0][j] = Bs[0][h][wn * (WTN * 32) + j * 32 + l32];
+  }
   for (int64_t kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
-    float fa[2][WTM], fb[2][WTN];
+    if constexpr (SCHED == 0) {
 #pragma unroll
-    for (int i = 0; i < WTM; ++i) fa[0][i] = As[cur][h][wm * (WTM * 32) + i * 32 + l32];
+      for (int i = 0; i < WTM; ++i) fa[0][i] = As[cur][h][wm * (WTM * 32) + i * 32 + l32];
 #pragma unroll
-    for (int j = 0; j < WTN; ++j) fb[0][j] = Bs[cur][h][wn * (WTN * 32) + j * 32 + l32];
+      for (int j = 0; j < WTN; ++j) fb[0][j] = Bs[cur][h][wn * (WTN * 32) + j * 32 + l32];
+    }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       const int c = (kk >> 1) & 1;
@@ -178,22 +191,52 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_mfma(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < WTN; ++j) fb[c ^ 1][j] = Bs[cur][kk + 2 + h][wn * (WTN * 32) + j * 32 + l32];
       }
-      if (kk == 0 && more) store_tile<BM, BK, NT, A_KC>(As[cur ^ 1], ra);
-      if (kk == 2 && more) store_tile<BN, BK, NT, B_KC>(Bs[cur ^ 1], rb);
-      if (kk == 4 && more2) {
-        load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 2) * BK, g.M, Kl, ra, vec_ok);
-        load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 2) * BK, g.N, Kl, rb, vec_ok);
+      if constexpr (SCHED == 0) {
+        if (kk == 0 && more) store_tile<BM, BK, NT, A_KC>(As[cur ^ 1], ra);
+        if (kk == 2 && more) store_tile<BN, BK, NT, B_KC>(Bs[cur ^ 1], rb);
+        if (kk == 4 && more2) {
+          load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 2) * BK, g.M, Kl, ra, vec_ok);
+          load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 2) * BK, g.N, Kl, rb, vec_ok);
+        }
+        // pin the order: staging and prefetch are issued ahead of this step's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        // branch-free body (the staging of the last two tiles is redundant, never wrong: the other
+        // LDS buffer is not read again, and the tile index is clamped) so that the whole k-tile is
+        // ONE scheduling region, and every MFMA is followed by a slice of the step's memory work
+        if (kk == 0) store_tile<BM, BK, NT, A_KC>(As[cur ^ 1], ra);
+        if (kk == 2) store_tile<BN, BK, NT, B_KC>(Bs[cur ^ 1], rb);
+        if (kk == 4) {
+          const int64_t ktl = more2 ? kt + 2 : nk - 1;
+          load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, ktl * BK, g.M, Kl, ra, vec_ok);
+          load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, ktl * BK, g.N, Kl, rb, vec_ok);
+        }
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < WTM * WTN; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // one LDS read (next step's fragments)
+          if (kk == 0 || kk == 2) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);  // LDS writes of the staged tile
+          if (kk == 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // one global load of tile kt+2
+        }
       }
-      // pin the order: staging and prefetch are issued ahead of this step's MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < WTM; ++i)
-#pragma unroll
-        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     cur ^= 1;
+    if constexpr (SCHED != 0) {  // (the last step's MFMAs are register-only and sink below the barrier: they cover these reads)
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) fa[0][i] = As[cur][h][wm * (WTM * 32) + i * 32 + l32];
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) fb[0][j] = Bs[cur][h][wn * (WTN * 32) + j * 32 + l32];
+    }
   }
 
   // C/D layout of the 32x32 accumulator: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -249,7 +292,7 @@ __global__ void __launch_bounds__(MD_BLOCK) k_gemm_splitk_sum(const float *__res
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int SCHED = 0>
 static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
   ga.tiles_m = (int)((ga.M + BM - 1) / BM);
   ga.tiles_n = (int)((ga.N + BN - 1) / BN);
@@ -287,7 +330,7 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
   }
   if (splits == 1) {
     if (edge) k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, true><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
-    else k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, false><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
+    else k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, false, false, SCHED><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
   }
   if (splits > 1) {
     k_gemm_splitk_sum<<<md_grid_for(batch * ga.M * ga.N), MD_BLOCK, 0, md_stream()>>>((const float *)partial, (int)splits, batch, ga.M, ga.N,
@@ -300,7 +343,7 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
 }
 
 // (128x128x32, 8-wave 256x128 and 256x256 tiles were measured and dropped: profiles/r1_gemm_tile_ab.log)
-enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_COUNT };
+enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_256x128x16_S0, CFG_128x64x16_S0, CFG_COUNT };
 
 static int pick_cfg(const GemmArgs &ga, int64_t batch) {
   if (const char *e = getenv("MDHIP_GEMM_CFG")) {  // experiments only
@@ -313,7 +356,7 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch) {
   // (4097 rows: 3 rounds of 256x128 against 17 of 64x64, i.e. 0.80x the time).
   if (((ga.M + 63) / 64) * ((ga.N + 63) / 64) * batch < MD_NUM_CUS && ga.K >= 1024) return CFG_64x64x16;  // split-K candidates
   struct Cand { int cfg, bm, bn; double tf; };
-  static const Cand cands[] = {{CFG_256x128x16, 256, 128, 136.0}, {CFG_128x128x16, 128, 128, 130.0},
+  static const Cand cands[] = {{CFG_256x128x16, 256, 128, 139.0}, {CFG_128x128x16, 128, 128, 133.0},
                                {CFG_128x64x16, 128, 64, 126.0}, {CFG_64x64x16, 64, 64, 120.0}};
   int best = CFG_64x64x16;
   double best_t = 1e300;
@@ -330,10 +373,12 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch) {
 template <bool A_KC, bool B_KC>
 static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
   switch (pick_cfg(ga, batch)) {
-    case CFG_64x64x16: return launch_cfg<64, 64, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
-    case CFG_128x64x16: return launch_cfg<128, 64, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
-    case CFG_256x128x16: return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
-    default: return launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC>(ga, batch, edge);
+    case CFG_64x64x16: return launch_cfg<64, 64, 16, 2, 2, A_KC, B_KC, 0>(ga, batch, edge);   // (2 MFMAs per step: nothing to interleave with; measured 6 % slower)
+    case CFG_128x64x16: return launch_cfg<128, 64, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
+    case CFG_256x128x16: return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
+    case CFG_256x128x16_S0: return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC, 0>(ga, batch, edge);
+    case CFG_128x64x16_S0: return launch_cfg<128, 64, 16, 2, 2, A_KC, B_KC, 0>(ga, batch, edge);
+    default: return launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
   }
 }
 
