@@ -343,9 +343,9 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
 }
 
 // (128x128x32, 8-wave 256x128 and 256x256 tiles were measured and dropped: profiles/r1_gemm_tile_ab.log)
-enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_256x128x16_S0, CFG_128x64x16_S0, CFG_COUNT };
+enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_256x128x16_S0, CFG_128x64x16_S0, CFG_256x256x32, CFG_COUNT };
 
-static int pick_cfg(const GemmArgs &ga, int64_t batch) {
+static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged) {
   if (const char *e = getenv("MDHIP_GEMM_CFG")) {  // experiments only
     int v = atoi(e);
     if (v >= 0 && v < CFG_COUNT) return v;
@@ -360,6 +360,13 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch) {
                                {CFG_128x64x16, 128, 64, 126.0}, {CFG_64x64x16, 64, 64, 120.0}};
   int best = CFG_64x64x16;
   double best_t = 1e300;
+  if (vector_staged) {  // TN: 256x256x32 measured 141.9 against 138.2 TFLOP/s (profiles/r1_gemm_tile_ab.log)
+    const int64_t tiles = ((ga.M + 255) / 256) * ((ga.N + 255) / 256) * batch;
+    if (tiles >= MD_NUM_CUS) {
+      best_t = (double)((tiles + MD_NUM_CUS - 1) / MD_NUM_CUS) * 256 * 256 / 141.5;
+      best = CFG_256x256x32;
+    }
+  }
   for (const Cand &c : cands) {
     const int64_t tiles = ((ga.M + c.bm - 1) / c.bm) * ((ga.N + c.bn - 1) / c.bn) * batch;
     const double rounds = (double)((tiles + MD_NUM_CUS - 1) / MD_NUM_CUS);
@@ -372,12 +379,15 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch) {
 
 template <bool A_KC, bool B_KC>
 static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
-  switch (pick_cfg(ga, batch)) {
+  switch (pick_cfg(ga, batch, !A_KC && !B_KC)) {
     case CFG_64x64x16: return launch_cfg<64, 64, 16, 2, 2, A_KC, B_KC, 0>(ga, batch, edge);   // (2 MFMAs per step: nothing to interleave with; measured 6 % slower)
     case CFG_128x64x16: return launch_cfg<128, 64, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
     case CFG_256x128x16: return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
     case CFG_256x128x16_S0: return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC, 0>(ga, batch, edge);
     case CFG_128x64x16_S0: return launch_cfg<128, 64, 16, 2, 2, A_KC, B_KC, 0>(ga, batch, edge);
+    case CFG_256x256x32:  // both operands staged with vector LDS stores (TN): one block per CU, half the barriers
+      if constexpr (!A_KC && !B_KC) return launch_cfg<256, 256, 32, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
+      else return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
     default: return launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
   }
 }
