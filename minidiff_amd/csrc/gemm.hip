@@ -500,14 +500,16 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f64_mfma(GemmArgs64 g) {
   }
   __syncthreads();
 
+  // same schedule as the f32 kernel: branch-free k-tile body, a slice of the step's memory work behind every
+  // MFMA, a tile's first fragments read right behind the barrier that publishes it
   int cur = 0;
+  double fa[2][WTM], fb[2][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) fa[0][i] = As[0][h][wm * (WTM * 16) + i * 16 + l16];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) fb[0][j] = Bs[0][h][wn * (WTN * 16) + j * 16 + l16];
   for (int64_t kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
-    double fa[2][WTM], fb[2][WTN];
-#pragma unroll
-    for (int i = 0; i < WTM; ++i) fa[0][i] = As[cur][h][wm * (WTM * 16) + i * 16 + l16];
-#pragma unroll
-    for (int j = 0; j < WTN; ++j) fb[0][j] = Bs[cur][h][wn * (WTN * 16) + j * 16 + l16];
+    const bool more2 = kt + 2 < nk;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
       const int c = (kk >> 2) & 1;
@@ -517,21 +519,31 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f64_mfma(GemmArgs64 g) {
 #pragma unroll
         for (int j = 0; j < WTN; ++j) fb[c ^ 1][j] = Bs[cur][kk + 4 + h][wn * (WTN * 16) + j * 16 + l16];
       }
-      if (kk == 0 && more) store_tile64<BM, BK, NT, A_KC>(As[cur ^ 1], ra);
-      if (kk == 4 && more) store_tile64<BN, BK, NT, B_KC>(Bs[cur ^ 1], rb);
-      if (kk == 8 && more2) {
-        load_tile64<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, (kt + 2) * BK, g.M, g.K, ra, vec_ok);
-        load_tile64<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, (kt + 2) * BK, g.N, g.K, rb, vec_ok);
+      if (kk == 0) store_tile64<BM, BK, NT, A_KC>(As[cur ^ 1], ra);
+      if (kk == 4) store_tile64<BN, BK, NT, B_KC>(Bs[cur ^ 1], rb);
+      if (kk == 8) {
+        const int64_t ktl = more2 ? kt + 2 : nk - 1;
+        load_tile64<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, ktl * BK, g.M, g.K, ra, vec_ok);
+        load_tile64<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, ktl * BK, g.N, g.K, rb, vec_ok);
       }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
         for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < WTM * WTN; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (kk == 0 || kk == 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if (kk == 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
     }
     __syncthreads();
     cur ^= 1;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) fa[0][i] = As[cur][h][wm * (WTM * 16) + i * 16 + l16];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) fb[0][j] = Bs[cur][h][wn * (WTN * 16) + j * 16 + l16];
   }
   // C/D of the f64 16x16 tile: col = lane&15, row = (lane>>4) + 4*r
 #pragma unroll
