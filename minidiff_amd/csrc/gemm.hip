@@ -343,7 +343,7 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
 }
 
 // (128x128x32, 8-wave 256x128 and 256x256 tiles were measured and dropped: profiles/r1_gemm_tile_ab.log)
-enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_256x128x16_S0, CFG_128x64x16_S0, CFG_256x256x32, CFG_COUNT };
+enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_256x128x16_S0, CFG_128x64x16_S0, CFG_256x256x32, CFG_128x128x32, CFG_128x64x32, CFG_COUNT };
 
 static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged) {
   if (const char *e = getenv("MDHIP_GEMM_CFG")) {  // experiments only
@@ -367,7 +367,10 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged) {
       best = CFG_256x256x32;
     }
   }
-  for (const Cand &c : cands) {
+  static const Cand cands_tn[] = {{CFG_256x128x16, 256, 128, 138.0}, {CFG_128x128x32, 128, 128, 132.0},
+                                  {CFG_128x64x32, 128, 64, 126.7}, {CFG_64x64x16, 64, 64, 120.0}};
+  for (int ci = 0; ci < 4; ++ci) {
+    const Cand &c = vector_staged ? cands_tn[ci] : cands[ci];
     const int64_t tiles = ((ga.M + c.bm - 1) / c.bm) * ((ga.N + c.bn - 1) / c.bn) * batch;
     const double rounds = (double)((tiles + MD_NUM_CUS - 1) / MD_NUM_CUS);
     double t = rounds * c.bm * c.bn / c.tf;
@@ -385,6 +388,15 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
     case CFG_256x128x16: return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
     case CFG_256x128x16_S0: return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC, 0>(ga, batch, edge);
     case CFG_128x64x16_S0: return launch_cfg<128, 64, 16, 2, 2, A_KC, B_KC, 0>(ga, batch, edge);
+    // deeper k-tiles for the small tiles of the TN layout: a k-tile of a small tile is too short to cover the
+    // global-load latency of the tile staged two ahead (2048^3 TN: 106 -> 117 TFLOP/s); the k-contiguous
+    // layouts are held back by their transposing LDS stores instead and gain nothing from it
+    case CFG_128x128x32:
+      if constexpr (!A_KC && !B_KC) return launch_cfg<128, 128, 32, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
+      else return launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
+    case CFG_128x64x32:
+      if constexpr (!A_KC && !B_KC) return launch_cfg<128, 64, 32, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
+      else return launch_cfg<128, 64, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
     case CFG_256x256x32:  // both operands staged with vector LDS stores (TN): one block per CU, half the barriers
       if constexpr (!A_KC && !B_KC) return launch_cfg<256, 256, 32, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
       else return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
