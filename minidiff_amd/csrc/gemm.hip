@@ -47,6 +47,7 @@ struct GemmArgs {
   int64_t M, N, K;
   int64_t a_bs, a_ms, a_ks, b_bs, b_ks, b_ns, c_bs, c_ms, c_ns;
   int tiles_m, tiles_n;
+  int super_h;  // tile rows per band of the XCD-compact numbering (0: plain row-major)
   int vec_ok;  // EDGE kernels: operands are 16-B aligned, so a fully inside vector may be loaded whole
   // split-K (gridDim.y > 1): block y multiplies k in [y*k_chunk, (y+1)*k_chunk) into its own
   // partial C (C + y*c_split), summed afterwards in split order by k_gemm_splitk_sum
@@ -121,7 +122,20 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_mfma(GemmArgs g) {
   const int nblk = g.tiles_m * g.tiles_n;
   int bid = blockIdx.x;
   if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-  const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+  int tm, tn;
+  if (g.super_h > 1) {
+    // tiles are numbered column-major inside bands of super_h tile rows, so that the nblk/8 consecutive
+    // ids of one XCD form a compact block (8 x 8 tiles at 4096^2 instead of 2 x 32): fewer distinct
+    // A/B panels per XCD L2, i.e. less L2 <- fabric traffic for the same work (speed-neutral: the
+    // kernel is not fabric-bound)
+    const int band = bid / (g.super_h * g.tiles_n), within = bid - band * (g.super_h * g.tiles_n);
+    const int hgt = (band + 1) * g.super_h <= g.tiles_m ? g.super_h : g.tiles_m - band * g.super_h;
+    tn = within / hgt;
+    tm = band * g.super_h + within - tn * hgt;
+  } else {
+    tm = bid / g.tiles_n;
+    tn = bid - tm * g.tiles_n;
+  }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const int64_t bz = blockIdx.z;
   const float *A = g.A + bz * g.a_bs;
@@ -297,6 +311,10 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
   ga.tiles_m = (int)((ga.M + BM - 1) / BM);
   ga.tiles_n = (int)((ga.N + BN - 1) / BN);
   ga.vec_ok = edge ? 0 : 1;  // `edge` on entry = operands not 16-B aligned
+  {
+    static const int sh = [] { const char *e = getenv("MDHIP_GEMM_SUPER"); return e ? atoi(e) : 8; }();
+    ga.super_h = (sh > 1 && ga.tiles_m >= sh && ga.tiles_n >= 8) ? sh : 0;
+  }
   edge = edge || (ga.M % BM) || (ga.N % BN) || (ga.K % BK);
   // split-K: a grid that cannot give every CU a block (skinny M or N with a long K, e.g. a
   // 64 x 4096 batch through a 4096 x 4096 layer) is widened along k; >= 512 k per split
