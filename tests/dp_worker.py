@@ -75,6 +75,40 @@ def main():
     assert np.array_equal(st2["A"].grad.as_numpy(), a_local)
     sync3.close()
     comm.allreduce_sum_ = real
+    # RcclComm's rendezvous: rank 0 creates the ncclUniqueId, every rank must call ncclCommInitRank with THAT id,
+    # its own rank and the world size (a recording stand-in for libmdhip: no collective runs here)
+    import ctypes as C
+    from minidiff_amd import _capi
+
+    class _Recorder:
+        def __init__(self):
+            self.calls = []
+
+        def comm_get_unique_id(self, uid):
+            for i in range(_capi.UID_BYTES):
+                uid[i] = (37 * i + 11) % 251
+            self.calls.append("get_unique_id")
+
+        def comm_init(self, nranks, r, uid):
+            self.calls.append(("init", nranks, r, bytes(uid)))
+
+        def comm_destroy(self):
+            self.calls.append("destroy")
+
+    rec = _Recorder()
+    real_load = _capi.load
+    _capi.load = lambda: rec
+    try:
+        rc = dp.RcclComm(rank, world, dist)
+        rc.close()
+    finally:
+        _capi.load = real_load
+    expected_uid = bytes((37 * i + 11) % 251 for i in range(_capi.UID_BYTES))
+    inits = [c for c in rec.calls if isinstance(c, tuple)]
+    assert inits == [("init", world, rank, expected_uid)], inits
+    assert ("get_unique_id" in rec.calls) == (rank == 0)
+    assert rec.calls[-1] == "destroy"
+
     dist.barrier()
     dist.destroy_process_group()
     print(f"DP-OK rank {rank}/{world}")
