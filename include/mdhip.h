@@ -291,7 +291,9 @@ int mdhip_vm_reduce(const mdhip_vm_program *prog, int reduce_op, const mdhip_arr
  * hiprtc for gfx950 and cached by signature; the interpreter remains the fallback
  * (small arrays, no libhiprtc, MDHIP_JIT=0). These two entry points are diagnostics:
  * compile-only check of a program (kind 0 = eval, 1 = full reduce, 2 = column
- * reduce; needs no device), and counters {kernels compiled, kernels launched}. */
+ * reduce (tiled), 3 = column reduce (sweep), 4 = eval + column reduce in one pass;
+ * needs no device), and counters {kernels compiled, kernels launched}. Generated
+ * kernels are named k_fused_<form>_<digest of the program signature>. */
 int mdhip_vm_jit_probe(const mdhip_vm_program *prog, int kind, int reduce_op, int out_is_bool,
                        char *log, size_t log_capacity);
 /* outs[k][...] = progs[k](...) for n programs of ONE shape (e.g. the gradients of one
@@ -299,6 +301,14 @@ int mdhip_vm_jit_probe(const mdhip_vm_program *prog, int kind, int reduce_op, in
  * 2..4 programs whose merged operand tables fit one launch, every distinct leaf is read once
  * and all results are written in the same pass; otherwise exactly n mdhip_vm_eval calls. */
 int mdhip_vm_eval_multi(const mdhip_vm_program *progs, const mdhip_array *outs, int n);
+/* out_eval[r][c] = prog(r, c) AND out_red[c] = reduce over r (reduce_op in {SUM, PROD, MAX, MIN}) of a 2-D
+ * program in ONE pass over its operands: the elementwise product of a backward step and its
+ * reduce-to-shape (cfg4: g * mask -> W-gradient operand, and its column sum -> bias gradient;
+ * reference call pattern minidiff/ops/definitions.py:555-559 then :157-183). Covered shapes:
+ * rows of 1024/2048/4096/8192 elements, >= 512 rows, with run-time specialisation available;
+ * anything else returns MDHIP_EVALUE and the caller runs the two passes separately. */
+int mdhip_vm_eval_reduce_cols(const mdhip_vm_program *prog, int reduce_op, const mdhip_array *out_eval,
+                              const mdhip_array *out_red);
 int mdhip_vm_jit_probe_multi(const mdhip_vm_program *progs, int n, char *log, size_t log_capacity);
 int mdhip_vm_jit_stats(int64_t stats[2]);
 

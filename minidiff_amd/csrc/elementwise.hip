@@ -16,6 +16,14 @@
 //            via a wave-uniform dtype switch; div/mod index walk.
 #include "md_hip.h"
 
+// independent vectors per lane and trip in the fast kernels (A/B: profiles/r2_ew_unroll_ab.log)
+#ifndef MD_EW_UNROLL
+#define MD_EW_UNROLL 2      // launches that stay inside the Infinity Cache (128 MiB operands: 1, 2, 4 within noise)
+#endif
+#ifndef MD_EW_UNROLL_NT
+#define MD_EW_UNROLL_NT 1   // non-temporal streams (> 320 MiB per launch): 400 MB multiply 214 us at 1, 238 at 2, 247 at 4
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------ generic ----
@@ -118,93 +126,154 @@ __device__ __forceinline__ Tc md_fast_load1(const FastOp<T> &o, Tc s, int64_t ro
   return md_cast<Tc>(o.p[row * o.os + (o.is ? c : 0)]);
 }
 
-__device__ __forceinline__ void md_row_col(int64_t v, int64_t nv, int64_t rows, int64_t &row, int64_t &cv) {
-  if (rows == 1) {
-    row = 0;
-    cv = v;
-  } else if ((uint64_t)v < 0x100000000ull && (uint64_t)nv < 0x100000000ull) {
-    uint32_t q = (uint32_t)v / (uint32_t)nv;
-    row = q;
-    cv = (uint32_t)v - q * (uint32_t)nv;
+// How an operand is read inside the loop is a COMPILE-TIME property of the kernel, so that the loads of one trip
+// are unconditional and issue back to back (with the three-way run-time branch of md_fast_load around every
+// load the compiler waited for each load before the next one: one load in flight per wave).
+//   OM_VEC   unit inner stride: one 16-B (f32/i32) / 2 x 16-B (f64/i64) / 4-B (bool) load per vector
+//   OM_SCAL  one value for the whole launch: a host scalar, or ONE device element behind a stride-0 view
+//            (the 0-d seed of the backward pass broadcast to the gradient's shape) read once in the prologue
+//   OM_FLEX  decided at run time per vector (column-broadcast operands: inner stride 0, row stride != 0)
+enum { OM_FLEX = 0, OM_VEC = 1, OM_SCAL = 2 };
+
+template <int MODE, bool NT, class T, class Tc>
+__device__ __forceinline__ void md_op_load(const FastOp<T> &o, Tc s, int64_t row, int64_t c, Tc (&r)[4]) {
+  if constexpr (MODE == OM_SCAL) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = s;
+  } else if constexpr (MODE == OM_VEC) {
+    MdVec<T, 4> v = md_ld_stream<NT>(reinterpret_cast<const MdVec<T, 4> *>(o.p + row * o.os + c));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = md_cast<Tc>(v.v[j]);
   } else {
-    row = v / nv;
-    cv = v - row * nv;
+    md_fast_load<NT>(o, s, row, c, r);
+  }
+}
+template <int MODE, class T, class Tc> __device__ __forceinline__ void md_op_prologue(const FastOp<T> &o, Tc &s) {
+  if constexpr (MODE == OM_SCAL) {
+    if (o.p != nullptr) s = md_cast<Tc>(o.p[0]);
   }
 }
 
-template <class F, class Tc, class To, class Tx, bool NT>
-__global__ void __launch_bounds__(MD_BLOCK) k_unary_fast(FastOp<Tx> x, Tc sx, To *out, int64_t rows, int64_t inner) {
-  const int64_t nv = inner >> 2, total = rows * nv;
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t v = gid; v < total; v += stride) {
-    int64_t row, cv;
-    md_row_col(v, nv, rows, row, cv);
-    const int64_t c = cv << 2;
-    Tc xv[4];
-    md_fast_load<NT>(x, sx, row, c, xv);
-    MdVec<To, 4> o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o.v[j] = md_to_out<To>(F::apply(xv[j]));
-    md_st_stream<NT>(reinterpret_cast<MdVec<To, 4> *>(out + row * inner + c), o);
-  }
-  if (rows == 1) {
-    const int64_t t0 = nv << 2;
-    if (gid < inner - t0) out[t0 + gid] = md_to_out<To>(F::apply(md_fast_load1(x, sx, 0, t0 + gid)));
-  }
-}
+// Launch geometry of the fast kernels: vectors of 4 elements over (rows, inner); thread t takes vectors
+// t, t + stride, t + 2 stride, ... . (dq, dr) = divmod(stride, inner / 4) from the host: the (row, column)
+// position advances by additions, one division per thread instead of one per vector.
+struct FastGrid {
+  int64_t rows, inner, dq, dr;
+};
 
-template <class F, class Tc, class To, class Ta, class Tb, bool NT>
-__global__ void __launch_bounds__(MD_BLOCK) k_binary_fast(FastOp<Ta> a, FastOp<Tb> b, Tc sa, Tc sb, To *out, int64_t rows, int64_t inner) {
-  const int64_t nv = inner >> 2, total = rows * nv;
+// U independent vectors per lane and trip: all loads of the U vectors are issued before the first use.
+template <int U, class Body> __device__ __forceinline__ void md_ew_drive(const Body &body, const FastGrid g) {
+  const int64_t nv = g.inner >> 2, total = g.rows * nv;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t v = gid; v < total; v += stride) {
-    int64_t row, cv;
-    md_row_col(v, nv, rows, row, cv);
-    const int64_t c = cv << 2;
-    Tc xv[4], yv[4];
-    md_fast_load<NT>(a, sa, row, c, xv);
-    md_fast_load<NT>(b, sb, row, c, yv);
-    MdVec<To, 4> o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o.v[j] = md_to_out<To>(F::apply(xv[j], yv[j]));
-    md_st_stream<NT>(reinterpret_cast<MdVec<To, 4> *>(out + row * inner + c), o);
-  }
-  if (rows == 1) {
-    const int64_t t0 = nv << 2;
-    if (gid < inner - t0)
-      out[t0 + gid] = md_to_out<To>(F::apply(md_fast_load1(a, sa, 0, t0 + gid), md_fast_load1(b, sb, 0, t0 + gid)));
-  }
-}
-
-template <class T, class Tcnd>
-__global__ void __launch_bounds__(MD_BLOCK) k_where_fast(FastOp<Tcnd> c, FastOp<T> a, FastOp<T> b, uint8_t sc, T sa, T sb, T *out,
-                                                        int64_t rows, int64_t inner) {
-  const int64_t nv = inner >> 2, total = rows * nv;
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t v = gid; v < total; v += stride) {
-    int64_t row, cv;
-    md_row_col(v, nv, rows, row, cv);
-    const int64_t col = cv << 2;
-    uint8_t cc[4];
-    T xv[4], yv[4];
-    md_fast_load(c, sc, row, col, cc);
-    md_fast_load(a, sa, row, col, xv);
-    md_fast_load(b, sb, row, col, yv);
-    MdVec<T, 4> o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o.v[j] = cc[j] ? xv[j] : yv[j];
-    *reinterpret_cast<MdVec<T, 4> *>(out + row * inner + col) = o;
-  }
-  if (rows == 1) {
-    const int64_t t0 = nv << 2;
-    if (gid < inner - t0) {
-      const int64_t i = t0 + gid;
-      out[i] = md_fast_load1(c, sc, 0, i) ? md_fast_load1(a, sa, 0, i) : md_fast_load1(b, sb, 0, i);
+  int64_t row = 0, cv = gid;
+  if (g.rows != 1) {
+    if ((uint64_t)gid < 0x100000000ull && (uint64_t)nv < 0x100000000ull) {
+      row = (uint32_t)gid / (uint32_t)nv;
+      cv = (uint32_t)gid - (uint32_t)row * (uint32_t)nv;
+    } else {
+      row = gid / nv;
+      cv = gid - row * nv;
     }
   }
+  auto advance = [&]() {
+    cv += g.dr;
+    row += g.dq;
+    if (cv >= nv) { cv -= nv; ++row; }
+  };
+  int64_t v = gid;
+  if constexpr (U > 1) {
+    for (; v + (U - 1) * stride < total; v += U * stride) {
+      typename Body::Regs r[U];
+      int64_t off[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        body.load(r[u], row, cv << 2);
+        off[u] = row * g.inner + (cv << 2);
+        advance();
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) body.store(r[u], off[u]);
+    }
+  }
+  for (; v < total; v += stride) {
+    typename Body::Regs r;
+    body.load(r, row, cv << 2);
+    body.store(r, row * g.inner + (cv << 2));
+    advance();
+  }
+  if (g.rows == 1) {  // 1-D: the up-to-3 elements behind the last whole vector
+    const int64_t i = (nv << 2) + gid;
+    if (i < g.inner) body.tail(i);
+  }
+}
+
+template <class F, class Tc, class To, class Tx, int MX, bool NT> struct UnaryBody {
+  FastOp<Tx> x;
+  Tc sx;
+  To *out;
+  struct Regs { Tc x[4]; };
+  __device__ __forceinline__ void prologue() { md_op_prologue<MX>(x, sx); }
+  __device__ __forceinline__ void load(Regs &r, int64_t row, int64_t c) const { md_op_load<MX, NT>(x, sx, row, c, r.x); }
+  __device__ __forceinline__ void store(const Regs &r, int64_t off) const {
+    MdVec<To, 4> o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = md_to_out<To>(F::apply(r.x[j]));
+    md_st_stream<NT>(reinterpret_cast<MdVec<To, 4> *>(out + off), o);
+  }
+  __device__ __forceinline__ void tail(int64_t i) const { out[i] = md_to_out<To>(F::apply(md_fast_load1(x, sx, 0, i))); }
+};
+
+template <class F, class Tc, class To, class Ta, class Tb, int MA, int MB, bool NT> struct BinaryBody {
+  FastOp<Ta> a;
+  FastOp<Tb> b;
+  Tc sa, sb;
+  To *out;
+  struct Regs { Tc x[4], y[4]; };
+  __device__ __forceinline__ void prologue() { md_op_prologue<MA>(a, sa); md_op_prologue<MB>(b, sb); }
+  __device__ __forceinline__ void load(Regs &r, int64_t row, int64_t c) const {
+    md_op_load<MA, NT>(a, sa, row, c, r.x);
+    md_op_load<MB, NT>(b, sb, row, c, r.y);
+  }
+  __device__ __forceinline__ void store(const Regs &r, int64_t off) const {
+    MdVec<To, 4> o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = md_to_out<To>(F::apply(r.x[j], r.y[j]));
+    md_st_stream<NT>(reinterpret_cast<MdVec<To, 4> *>(out + off), o);
+  }
+  __device__ __forceinline__ void tail(int64_t i) const {
+    out[i] = md_to_out<To>(F::apply(md_fast_load1(a, sa, 0, i), md_fast_load1(b, sb, 0, i)));
+  }
+};
+
+template <class T, class Tcnd, int MC, int MA, int MB> struct WhereBody {
+  FastOp<Tcnd> c;
+  FastOp<T> a, b;
+  uint8_t sc;
+  T sa, sb;
+  T *out;
+  struct Regs { uint8_t c[4]; T x[4], y[4]; };
+  __device__ __forceinline__ void prologue() { md_op_prologue<MC>(c, sc); md_op_prologue<MA>(a, sa); md_op_prologue<MB>(b, sb); }
+  __device__ __forceinline__ void load(Regs &r, int64_t row, int64_t col) const {
+    md_op_load<MC, false>(c, sc, row, col, r.c);
+    md_op_load<MA, false>(a, sa, row, col, r.x);
+    md_op_load<MB, false>(b, sb, row, col, r.y);
+  }
+  __device__ __forceinline__ void store(const Regs &r, int64_t off) const {
+    MdVec<T, 4> o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = r.c[j] ? r.x[j] : r.y[j];
+    *reinterpret_cast<MdVec<T, 4> *>(out + off) = o;
+  }
+  __device__ __forceinline__ void tail(int64_t i) const {
+    out[i] = md_fast_load1(c, sc, 0, i) ? md_fast_load1(a, sa, 0, i) : md_fast_load1(b, sb, 0, i);
+  }
+};
+
+// One kernel for all three arities; the profiler shows the body type (operator, types, operand modes).
+template <class Body, int U> __global__ void __launch_bounds__(MD_BLOCK) k_ew_fast(Body body, FastGrid g) {
+  body.prologue();
+  md_ew_drive<U>(body, g);
 }
 
 // ------------------------------------------------------------- transposed x ----
@@ -309,8 +378,38 @@ static int nt_for(int64_t bytes) {
   return bytes > ((int64_t)320 << 20);
 }
 
+// compile-time read mode an operand qualifies for (OM_FLEX: only the run-time path can read it)
+template <class T> static int fast_mode(const FastOp<T> &f, const FastGeom &g) {
+  if (f.p == nullptr) return OM_SCAL;
+  if (f.is) return OM_VEC;
+  return (f.os == 0 || g.rows == 1) ? OM_SCAL : OM_FLEX;
+}
+template <class T> static int64_t fast_bytes(const FastOp<T> &f, const FastGeom &g) {
+  if (f.p == nullptr || !f.is) return 0;
+  return (f.os == 0 && g.rows > 1 ? g.inner : g.rows * g.inner) * (int64_t)sizeof(T);
+}
+
+template <class Body, int U> static int launch_fast(const Body &body, const FastGeom &g, const char *what) {
+  const int64_t nv = g.inner >> 2;
+  const int64_t work = g.rows * nv + (g.rows == 1 ? 4 : 0);
+  const int grid = md_grid_for(work);
+  const int64_t stride = (int64_t)grid * MD_BLOCK;
+  FastGrid fg;
+  fg.rows = g.rows;
+  fg.inner = g.inner;
+  fg.dq = nv > 0 ? stride / nv : 0;
+  fg.dr = nv > 0 ? stride % nv : 0;
+  k_ew_fast<Body, U><<<grid, MD_BLOCK, 0, md_stream()>>>(body, fg);
+  return MD_LAUNCH_CHECK(what);
+}
+
 struct HipExec {
   // ------------------------------------------------------------------ unary ----
+  template <class F, class Tc, class To, class Tx, int MX>
+  static int unary_fast(const FastOp<Tx> &fx, Tc sx, To *out, const FastGeom &g, bool nt) {
+    if (nt) return launch_fast<UnaryBody<F, Tc, To, Tx, MX, true>, MD_EW_UNROLL_NT>(UnaryBody<F, Tc, To, Tx, MX, true>{fx, sx, out}, g, "unary(fast)");
+    return launch_fast<UnaryBody<F, Tc, To, Tx, MX, false>, MD_EW_UNROLL>(UnaryBody<F, Tc, To, Tx, MX, false>{fx, sx, out}, g, "unary(fast)");
+  }
   template <class F, class Tc, class To>
   static int unary(const MdIter &it, const mdhip_array *x, const mdhip_array *out) {
     using Tx = typename md_storage<Tc>::type;
@@ -319,24 +418,22 @@ struct HipExec {
     FastGeom g;
     FastOp<Tx> fx;
     if (fast_geom(it, 1, &g) && fast_aligned<To>(out->data) && fast_operand<Tx>(it, 0, x, g, &fx)) {
-      const int64_t work = g.rows * (g.inner >> 2) + (g.rows == 1 ? 4 : 0);
-      const int64_t bytes = g.rows * g.inner * (int64_t)(sizeof(To) + (fx.p && fx.is ? sizeof(Tx) : 0));
-      if (nt_for(bytes)) k_unary_fast<F, Tc, To, Tx, true><<<md_grid_for(work), MD_BLOCK, 0, st>>>(fx, sx, (To *)out->data, g.rows, g.inner);
-      else k_unary_fast<F, Tc, To, Tx, false><<<md_grid_for(work), MD_BLOCK, 0, st>>>(fx, sx, (To *)out->data, g.rows, g.inner);
-      return MD_LAUNCH_CHECK("unary(fast)");
+      const bool nt = nt_for(g.rows * g.inner * (int64_t)sizeof(To) + fast_bytes(fx, g));
+      switch (fast_mode(fx, g)) {
+        case OM_VEC: return unary_fast<F, Tc, To, Tx, OM_VEC>(fx, sx, (To *)out->data, g, nt);
+        case OM_SCAL: return unary_fast<F, Tc, To, Tx, OM_SCAL>(fx, sx, (To *)out->data, g, nt);
+        default: return launch_fast<UnaryBody<F, Tc, To, Tx, OM_FLEX, false>, 1>(UnaryBody<F, Tc, To, Tx, OM_FLEX, false>{fx, sx, (To *)out->data}, g, "unary(fast,flex)");
+      }
     }
     // dtype conversions (astype, definitions.py:429-432; raw .astype, tensor.py:105): the same streaming
     // kernel with the SOURCE storage type as the load type
     if constexpr (md_same<F, UCopy>::value) {
       if (!x->is_scalar && x->dtype != md_dtype_of<Tx>::value && fast_geom(it, 1, &g) && fast_aligned<To>(out->data)) {
-        const int64_t work = g.rows * (g.inner >> 2) + (g.rows == 1 ? 4 : 0);
 #define MD_CAST_FROM(S)                                                                                                   \
         {                                                                                                                 \
           FastOp<S> fs;                                                                                                   \
-          if (fast_operand<S>(it, 0, x, g, &fs)) {                                                                        \
-            k_unary_fast<F, Tc, To, S, false><<<md_grid_for(work), MD_BLOCK, 0, st>>>(fs, sx, (To *)out->data, g.rows, g.inner); \
-            return MD_LAUNCH_CHECK("unary(fast,cast)");                                                                   \
-          }                                                                                                               \
+          if (fast_operand<S>(it, 0, x, g, &fs) && fast_mode(fs, g) == OM_VEC)                                            \
+            return launch_fast<UnaryBody<F, Tc, To, S, OM_VEC, false>, MD_EW_UNROLL>(UnaryBody<F, Tc, To, S, OM_VEC, false>{fs, sx, (To *)out->data}, g, "unary(fast,cast)"); \
         }
         switch (x->dtype) {
           case MDHIP_F32: MD_CAST_FROM(float) break;
@@ -359,17 +456,29 @@ struct HipExec {
   }
 
   // ----------------------------------------------------------------- binary ----
+  template <class F, class Tc, class To, class Ta, class Tb, int MA, int MB>
+  static int binary_fast(const FastOp<Ta> &fa, const FastOp<Tb> &fb, Tc sa, Tc sb, To *out, const FastGeom &g, bool nt) {
+    if (nt) return launch_fast<BinaryBody<F, Tc, To, Ta, Tb, MA, MB, true>, MD_EW_UNROLL_NT>(BinaryBody<F, Tc, To, Ta, Tb, MA, MB, true>{fa, fb, sa, sb, out}, g, "binary(fast)");
+    return launch_fast<BinaryBody<F, Tc, To, Ta, Tb, MA, MB, false>, MD_EW_UNROLL>(BinaryBody<F, Tc, To, Ta, Tb, MA, MB, false>{fa, fb, sa, sb, out}, g, "binary(fast)");
+  }
   template <class F, class Tc, class To, class Ta, class Tb>
   static bool try_binary_fast(const MdIter &it, const FastGeom &g, const mdhip_array *a, const mdhip_array *b,
                               const mdhip_array *out, Tc sa, Tc sb, int *status) {
     FastOp<Ta> fa;
     FastOp<Tb> fb;
     if (!fast_operand<Ta>(it, 0, a, g, &fa) || !fast_operand<Tb>(it, 1, b, g, &fb)) return false;
-    const int64_t work = g.rows * (g.inner >> 2) + (g.rows == 1 ? 4 : 0);
-    const int64_t bytes = g.rows * g.inner * (int64_t)(sizeof(To) + (fa.p && fa.is ? sizeof(Ta) : 0) + (fb.p && fb.is ? sizeof(Tb) : 0));
-    if (nt_for(bytes)) k_binary_fast<F, Tc, To, Ta, Tb, true><<<md_grid_for(work), MD_BLOCK, 0, md_stream()>>>(fa, fb, sa, sb, (To *)out->data, g.rows, g.inner);
-    else k_binary_fast<F, Tc, To, Ta, Tb, false><<<md_grid_for(work), MD_BLOCK, 0, md_stream()>>>(fa, fb, sa, sb, (To *)out->data, g.rows, g.inner);
-    *status = MD_LAUNCH_CHECK("binary(fast)");
+    const bool nt = nt_for(g.rows * g.inner * (int64_t)sizeof(To) + fast_bytes(fa, g) + fast_bytes(fb, g));
+    To *o = (To *)out->data;
+    const int ma = fast_mode(fa, g), mb = fast_mode(fb, g);
+    // the three streaming forms get their own kernels for the float loops (everything BASELINE's graphs launch);
+    // integer loops and column-broadcast operands take the run-time path
+    if constexpr (md_is_float<Tc>::value) {
+      if (ma == OM_VEC && mb == OM_VEC) { *status = binary_fast<F, Tc, To, Ta, Tb, OM_VEC, OM_VEC>(fa, fb, sa, sb, o, g, nt); return true; }
+      if (ma == OM_VEC && mb == OM_SCAL) { *status = binary_fast<F, Tc, To, Ta, Tb, OM_VEC, OM_SCAL>(fa, fb, sa, sb, o, g, nt); return true; }
+      if (ma == OM_SCAL && mb == OM_VEC) { *status = binary_fast<F, Tc, To, Ta, Tb, OM_SCAL, OM_VEC>(fa, fb, sa, sb, o, g, nt); return true; }
+    }
+    using Body = BinaryBody<F, Tc, To, Ta, Tb, OM_FLEX, OM_FLEX, false>;
+    *status = launch_fast<Body, 1>(Body{fa, fb, sa, sb, o}, g, "binary(fast,flex)");
     return true;
   }
   template <class F, class Tc, class To>
@@ -403,9 +512,20 @@ struct HipExec {
     FastOp<T> fa, fb;
     if (fast_geom(it, 3, &g) && fast_aligned<T>(out->data) && fast_operand<b8>(it, 0, c, g, &fc) &&
         fast_operand<T>(it, 1, a, g, &fa) && fast_operand<T>(it, 2, b, g, &fb)) {
-      const int64_t work = g.rows * (g.inner >> 2) + (g.rows == 1 ? 4 : 0);
-      k_where_fast<T, b8><<<md_grid_for(work), MD_BLOCK, 0, md_stream()>>>(fc, fa, fb, sc, sa, sb, (T *)out->data, g.rows, g.inner);
-      return MD_LAUNCH_CHECK("where(fast)");
+      T *o = (T *)out->data;
+      const int mc = fast_mode(fc, g), ma = fast_mode(fa, g), mb = fast_mode(fb, g);
+#define MD_WHERE_FORM(MA_, MB_)                                                                                             \
+      if (mc == OM_VEC && ma == MA_ && mb == MB_) {                                                                         \
+        using Body = WhereBody<T, b8, OM_VEC, MA_, MB_>;                                                                    \
+        return launch_fast<Body, MD_EW_UNROLL>(Body{fc, fa, fb, sc, sa, sb, o}, g, "where(fast)");                          \
+      }
+      MD_WHERE_FORM(OM_VEC, OM_SCAL)   // relu := where(z > 0, z, 0)
+      MD_WHERE_FORM(OM_SCAL, OM_VEC)
+      MD_WHERE_FORM(OM_VEC, OM_VEC)
+      MD_WHERE_FORM(OM_SCAL, OM_SCAL)  // mod_grad: where(x % y == 0, 0, grad) with a broadcast seed
+#undef MD_WHERE_FORM
+      using Body = WhereBody<T, b8, OM_FLEX, OM_FLEX, OM_FLEX>;
+      return launch_fast<Body, 1>(Body{fc, fa, fb, sc, sa, sb, o}, g, "where(fast,flex)");
     }
     k_where_generic<T><<<md_grid_for(it.total), MD_BLOCK, 0, md_stream()>>>(
         it, c->data, c->dtype, c->is_scalar, sc, a->data, a->dtype, a->is_scalar, sa, b->data, b->dtype, b->is_scalar, sb,

@@ -305,6 +305,8 @@ __global__ void __launch_bounds__(MD_BLOCK) k_vm_reduce_cols(MdVmDev P, int64_t 
   }
 }
 
+#include "md_cols_merge.h"
+
 }  // namespace
 #include "fusion_jit.inc"
 namespace {
@@ -364,11 +366,18 @@ template <class T> static int eval_typed(const mdhip_vm_program *pr, const mdhip
       int64_t bytes = it.total * (int64_t)md_dtype_size(out->dtype);
       for (int l = 0; l < pr->n_leaves; ++l)
         if (D.leaf[l].is) bytes += it.total * (int64_t)md_dtype_size(pr->leaves[l].dtype);
-      if (hipFunction_t fn = jit::get(pr, jit::EVAL, 0, to_bool, bytes > ((int64_t)320 << 20))) {
+      jit::Spec S;
+      S.kind = jit::EVAL;
+      jit::spec_single(&S, pr);
+      jit::spec_modes(&S, D, rows);
+      S.out_bool = to_bool;
+      S.nt = bytes > ((int64_t)320 << 20);
+      if (hipFunction_t fn = jit::get(S)) {
         jit::JArgs A;
         jit::fill_args(&A, pr, D);
-        A.out = out->data; A.rows = rows; A.inner = inner;
-        return jit::launch(fn, A, dim3((unsigned)md_grid_for(rows * (inner >> 2) + (rows == 1 ? 4 : 0))));
+        A.outs[0] = out->data;
+        const int grid = jit::stream_grid(&A, rows, inner);
+        return jit::launch(fn, A, dim3((unsigned)grid));
       }
     }
     const int64_t work = (rows * (inner >> 2) + VG - 1) / VG + (rows == 1 ? 4 : 0);
@@ -383,9 +392,13 @@ template <class T> static int eval_typed(const mdhip_vm_program *pr, const mdhip
 
 // merge the leaf tables of n programs (identical descriptors share a slot) and give every
 // immediate its slot in the shared array; false if the bounds of one launch are exceeded
-static bool merge_programs(const mdhip_vm_program *progs, int n, jit::Multi *M, mdhip_vm_program *merged) {
+static bool merge_programs(const mdhip_vm_program *progs, int n, jit::Spec *M, mdhip_vm_program *merged) {
   if (n < 2 || n > 4) return false;
+  M->kind = jit::EVAL;
   M->n = n;
+  M->n_leaves = 0;
+  M->n_imm = 0;
+  M->f32 = progs[0].compute_dtype == MDHIP_F32;
   memset(merged, 0, sizeof *merged);
   merged->compute_dtype = progs[0].compute_dtype;
   for (int k = 0; k < n; ++k) {
@@ -430,7 +443,7 @@ static bool merge_programs(const mdhip_vm_program *progs, int n, jit::Multi *M, 
 static int eval_multi(const mdhip_vm_program *progs, const mdhip_array *outs, int n, bool *done) {
   *done = false;
   if (!jit::enabled()) return MDHIP_OK;
-  jit::Multi M;
+  jit::Spec M;
   mdhip_vm_program merged;
   if (!merge_programs(progs, n, &M, &merged)) return MDHIP_OK;
   for (int k = 0; k < n; ++k) {  // outputs: the compute dtype, contiguous, one shape
@@ -449,19 +462,75 @@ static int eval_multi(const mdhip_vm_program *progs, const mdhip_array *outs, in
   int64_t bytes = (int64_t)n * it.total * (int64_t)md_dtype_size(merged.compute_dtype);
   for (int l = 0; l < merged.n_leaves; ++l)
     if (D.leaf[l].is) bytes += it.total * (int64_t)md_dtype_size(merged.leaves[l].dtype);
-  hipFunction_t fn = jit::get_multi(M, bytes > ((int64_t)320 << 20));
+  jit::spec_modes(&M, D, rows);
+  M.nt = bytes > ((int64_t)320 << 20);
+  hipFunction_t fn = jit::get(M);
   if (!fn) return MDHIP_OK;
   jit::JArgs A;
   memset(&A, 0, sizeof A);
   for (int l = 0; l < merged.n_leaves; ++l) { A.leaf[l].p = D.leaf[l].p; A.leaf[l].os = D.leaf[l].os; A.leaf[l].is = D.leaf[l].is; }
   for (int i = 0; i < M.n_imm; ++i) A.imm[i] = merged.imm[i];
   for (int k = 0; k < n; ++k) A.outs[k] = outs[k].data;
-  A.rows = rows; A.inner = inner;
+  const int grid = jit::stream_grid(&A, rows, inner);
   *done = true;
-  return jit::launch(fn, A, dim3((unsigned)md_grid_for(rows * (inner >> 2) + (rows == 1 ? 4 : 0))));
+  return jit::launch(fn, A, dim3((unsigned)grid));
 }
 
 static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Sweep geometry for a (n_red x n_out) program: n_out = Q x 1024 elements (Q column vectors per lane of a 256-thread
+// block), a contiguous band of rows per block, one block per CU.
+static bool sweep_geometry(int64_t n_out, int64_t n_red, int *Q, int64_t *nblk, int64_t *chunk) {
+  if (n_out % 1024 || n_red < 512) return false;
+  const int64_t q = n_out / 1024;
+  if (q != 1 && q != 2 && q != 4 && q != 8) return false;
+  *Q = (int)q;
+  int64_t nb = MD_NUM_CUS;
+  if (nb > n_red / 6) nb = n_red / 6;
+  *chunk = (n_red + nb - 1) / nb;
+  *nblk = (n_red + *chunk - 1) / *chunk;
+  return true;
+}
+
+// reduce over axis 0 of a 2-D program with the generated sweep kernel; `eval_out` != nullptr: the evaluated value
+// is written as well (one pass for an elementwise product and its reduce-to-shape). false: not applicable.
+template <class R, class T>
+static bool sweep_cols(const mdhip_vm_program *pr, int rop, const MdVmDev &D, int64_t rows, int64_t inner, void *eval_out,
+                       const mdhip_array *out, int *status) {
+  int Q;
+  int64_t nblk, chunk;
+  if (!jit::enabled() || rows * inner < jit::min_elems() || !sweep_geometry(inner, rows, &Q, &nblk, &chunk)) return false;
+  jit::Spec S;
+  S.kind = jit::SWEEP;
+  jit::spec_single(&S, pr);
+  jit::spec_modes(&S, D, rows);
+  S.rop = rop;
+  S.store = eval_out != nullptr;
+  S.Q = Q;
+  int n_vec = 0;
+  int64_t bytes = eval_out ? rows * inner * (int64_t)sizeof(T) : 0;
+  for (int l = 0; l < pr->n_leaves; ++l)
+    if (S.leaf_mode[l] == jit::LM_VEC) { ++n_vec; bytes += rows * inner * (int64_t)md_dtype_size(pr->leaves[l].dtype); }
+  S.RU = n_vec * Q <= 4 ? 3 : (n_vec * Q <= 8 ? 2 : 1);  // ~12 x 16 B of loads in flight per lane
+  S.nt = bytes > ((int64_t)320 << 20);
+  hipFunction_t fn = jit::get(S);
+  if (!fn) return false;
+  void *partial = nullptr;
+  *status = mdhip_alloc((size_t)(nblk * inner) * sizeof(T), &partial);
+  if (*status != MDHIP_OK) return true;
+  jit::JArgs A;
+  jit::fill_args(&A, pr, D);
+  A.rows = rows; A.inner = inner; A.n_out = inner; A.n_red = rows; A.chunk = chunk;
+  A.out = partial;
+  A.outs[0] = eval_out;
+  *status = jit::launch(fn, A, dim3((unsigned)nblk));
+  if (*status == MDHIP_OK) {
+    k_reduce_cols_merge<R, T, T><<<(unsigned)((inner + 63) / 64), 1024, 0, md_stream()>>>((const T *)partial, inner, nblk, (T *)out->data);
+    *status = MD_LAUNCH_CHECK("vm_reduce(cols,sweep)");
+  }
+  mdhip_free(partial);
+  return true;
+}
 
 template <class R, class T>
 static int reduce_typed(const mdhip_vm_program *pr, int rop, const mdhip_array *shape_like, const mdhip_array *out, uint32_t mask) {
@@ -480,16 +549,28 @@ static int reduce_typed(const mdhip_vm_program *pr, int rop, const mdhip_array *
     int64_t rbytes = 0;
     for (int l = 0; l < pr->n_leaves; ++l)
       if (D.leaf[l].is) rbytes += it.total * (int64_t)md_dtype_size(pr->leaves[l].dtype);
-    hipFunction_t fn = (jit::enabled() && it.total >= jit::min_elems())
-                           ? jit::get(pr, jit::RED_ALL, rop, false, rbytes > ((int64_t)320 << 20)) : nullptr;
-    const int64_t work = fn ? rows * (inner >> 2) + (rows == 1 ? 4 : 0) : (rows * (inner >> 2) + VG - 1) / VG + (rows == 1 ? 4 : 0);
-    const int grid = md_grid_for(work);
+    hipFunction_t fn = nullptr;
+    if (jit::enabled() && it.total >= jit::min_elems()) {
+      jit::Spec S;
+      S.kind = jit::RED_ALL;
+      jit::spec_single(&S, pr);
+      jit::spec_modes(&S, D, rows);
+      S.rop = rop;
+      S.nt = rbytes > ((int64_t)320 << 20);
+      fn = jit::get(S);
+    }
+    jit::JArgs A;
+    int grid;
+    if (fn) {
+      jit::fill_args(&A, pr, D);
+      grid = jit::stream_grid(&A, rows, inner);
+    } else {
+      grid = md_grid_for((rows * (inner >> 2) + VG - 1) / VG + (rows == 1 ? 4 : 0));
+    }
     void *partial = nullptr;
     MD_TRY(mdhip_alloc((size_t)grid * sizeof(T), &partial));
     if (fn) {
-      jit::JArgs A;
-      jit::fill_args(&A, pr, D);
-      A.out = partial; A.rows = rows; A.inner = inner;
+      A.out = partial;
       int rc = jit::launch(fn, A, dim3((unsigned)grid));
       if (rc != MDHIP_OK) { mdhip_free(partial); return rc; }
     } else {
@@ -502,6 +583,8 @@ static int reduce_typed(const mdhip_vm_program *pr, int rop, const mdhip_array *
   }
   // reduce over axis 0 of a 2-D program that did NOT collapse to 1-D
   if (nd == 2 && mask == 1u && it.ndim == 2 && shape_like->shape[0] == rows && shape_like->shape[1] == inner) {
+    int status = MDHIP_OK;
+    if (sweep_cols<R, T>(pr, rop, D, rows, inner, nullptr, out, &status)) return status;
     const int64_t n_out = inner, n_red = rows;
     const int64_t bx = ceil_div(n_out, 256);
     int64_t splits = 1024 / bx;
@@ -510,7 +593,15 @@ static int reduce_typed(const mdhip_vm_program *pr, int rop, const mdhip_array *
     if (splits < 1) splits = 1;
     const int64_t chunk = ceil_div(ceil_div(n_red, splits), 16) * 16;
     splits = ceil_div(n_red, chunk);
-    hipFunction_t fn = (jit::enabled() && it.total >= jit::min_elems()) ? jit::get(pr, jit::RED_COLS, rop, false) : nullptr;
+    hipFunction_t fn = nullptr;
+    if (jit::enabled() && it.total >= jit::min_elems()) {
+      jit::Spec S;
+      S.kind = jit::RED_COLS;
+      jit::spec_single(&S, pr);
+      jit::spec_modes(&S, D, rows);
+      S.rop = rop;
+      fn = jit::get(S);
+    }
     jit::JArgs A;
     if (fn) {
       jit::fill_args(&A, pr, D);
@@ -545,6 +636,38 @@ static int reduce_typed(const mdhip_vm_program *pr, int rop, const mdhip_array *
   return md_fail(MDHIP_EVALUE, "vm_reduce: only full reductions and axis-0 reductions of 2-D programs are fused");
 }
 
+// out_eval[r][c] = program(r, c) and out_red[c] = reduce over r, ONE pass (generated sweep kernel only)
+template <class R, class T>
+static int eval_reduce_cols_typed(const mdhip_vm_program *pr, int rop, const mdhip_array *out_eval, const mdhip_array *out_red) {
+  MdVmIter it;
+  MD_TRY(md_vm_build_iter(&it, pr, out_eval, out_eval));
+  if (it.total == 0 || out_eval->ndim != 2) return md_fail(MDHIP_EVALUE, "vm_eval_reduce_cols: a non-empty 2-D program is required");
+  MdVmDev D;
+  to_dev(pr, &D);
+  int64_t rows, inner;
+  if (!fast_geometry(it, pr->n_leaves, pr, true, &D, &rows, &inner) || it.ndim != 2 || rows != out_eval->shape[0] || inner != out_eval->shape[1])
+    return md_fail(MDHIP_EVALUE, "vm_eval_reduce_cols: geometry not supported");
+  if (((uintptr_t)out_eval->data & 15) || ((uintptr_t)out_red->data & 15)) return md_fail(MDHIP_EVALUE, "vm_eval_reduce_cols: unaligned output");
+  int status = MDHIP_OK;
+  if (sweep_cols<R, T>(pr, rop, D, rows, inner, out_eval->data, out_red, &status)) return status;
+  return md_fail(MDHIP_EVALUE, "vm_eval_reduce_cols: shape not covered by the one-pass kernel");
+}
+
+// compile-only probes have no launch geometry: read modes from the leaf descriptors as given
+static void probe_modes(jit::Spec *S, const mdhip_vm_program *pr) {
+  for (int l = 0; l < pr->n_leaves; ++l) {
+    const mdhip_array &a = pr->leaves[l];
+    bool all0 = true;
+    for (int d = 0; d < a.ndim; ++d) all0 = all0 && (a.strides[d] == 0 || a.shape[d] == 1);
+    const bool inner0 = a.ndim == 0 || a.strides[a.ndim - 1] == 0;
+    const int slot = S->leaf_map[0][l];
+    if (all0) S->leaf_mode[slot] = jit::LM_CONST;
+    else if (inner0) S->leaf_mode[slot] = jit::LM_ROWB;
+    else if (S->kind == jit::SWEEP && a.ndim == 2 && a.strides[0] == 0) S->leaf_mode[slot] = jit::LM_ROWINV;
+    else S->leaf_mode[slot] = jit::LM_VEC;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -572,12 +695,19 @@ int mdhip_vm_eval_multi(const mdhip_vm_program *progs, const mdhip_array *outs, 
 
 int mdhip_vm_jit_probe_multi(const mdhip_vm_program *progs, int n, char *log, size_t log_cap) {
   for (int k = 0; k < n; ++k) MD_TRY(md_vm_check(&progs[k]));
-  jit::Multi M;
+  jit::Spec M;
   mdhip_vm_program merged;
   if (!merge_programs(progs, n, &M, &merged)) return md_fail(MDHIP_EVALUE, "jit probe: programs cannot share one launch");
+  for (int k = 0; k < n; ++k) {
+    jit::Spec one;
+    one.kind = jit::EVAL;
+    for (int l = 0; l < progs[k].n_leaves; ++l) one.leaf_map[0][l] = M.leaf_map[k][l];
+    probe_modes(&one, &progs[k]);
+    for (int l = 0; l < progs[k].n_leaves; ++l) M.leaf_mode[M.leaf_map[k][l]] = one.leaf_mode[M.leaf_map[k][l]];
+  }
   std::vector<char> code;
   std::string l;
-  const int rc = jit::compile(jit::gen_source_multi(M, false), &code, &l);
+  const int rc = jit::compile(jit::gen_source(M, "k_fused_probe"), &code, &l);
   if (log && log_cap) { strncpy(log, l.c_str(), log_cap - 1); log[log_cap - 1] = 0; }
   if (rc != 0) return md_fail(MDHIP_ERUNTIME, "fused-kernel compilation failed: %.300s", l.c_str());
   return MDHIP_OK;
@@ -585,13 +715,42 @@ int mdhip_vm_jit_probe_multi(const mdhip_vm_program *progs, int n, char *log, si
 
 int mdhip_vm_jit_probe(const mdhip_vm_program *pr, int kind, int reduce_op, int out_is_bool, char *log, size_t log_cap) {
   MD_TRY(md_vm_check(pr));
-  if (kind < 0 || kind > 2) return md_fail(MDHIP_EVALUE, "jit probe: kind must be 0 (eval), 1 (reduce all) or 2 (reduce columns)");
+  if (kind < 0 || kind > 4)
+    return md_fail(MDHIP_EVALUE, "jit probe: kind must be 0 (eval), 1 (reduce all), 2 (reduce columns, tiled), 3 (reduce columns, sweep) or 4 (eval + reduce columns)");
+  jit::Spec S;
+  S.kind = kind >= 3 ? jit::SWEEP : kind;
+  jit::spec_single(&S, pr);
+  probe_modes(&S, pr);
+  S.rop = reduce_op;
+  S.out_bool = out_is_bool != 0 && kind == 0;
+  S.store = kind == 4;
+  S.Q = 4;
+  S.RU = 2;
   std::vector<char> code;
   std::string l;
-  const int rc = jit::compile(jit::gen_source(pr, kind, reduce_op, out_is_bool != 0), &code, &l);
+  const int rc = jit::compile(jit::gen_source(S, "k_fused_probe"), &code, &l);
   if (log && log_cap) { strncpy(log, l.c_str(), log_cap - 1); log[log_cap - 1] = 0; }
   if (rc != 0) return md_fail(MDHIP_ERUNTIME, "fused-kernel compilation failed: %.300s", l.c_str());
   return MDHIP_OK;
+}
+
+int mdhip_vm_eval_reduce_cols(const mdhip_vm_program *pr, int op, const mdhip_array *out_eval, const mdhip_array *out_red) {
+  MD_TRY(md_vm_check(pr));
+  MD_TRY(md_check_array(out_eval, "vm out"));
+  MD_TRY(md_check_array(out_red, "vm out"));
+  if (out_eval->dtype != pr->compute_dtype || out_red->dtype != pr->compute_dtype)
+    return md_fail(MDHIP_ETYPE, "vm_eval_reduce_cols: both outputs must have the compute dtype");
+#define MD_VMER(R)                                                                                        \
+  return pr->compute_dtype == MDHIP_F32 ? eval_reduce_cols_typed<R, float>(pr, op, out_eval, out_red)     \
+                                        : eval_reduce_cols_typed<R, double>(pr, op, out_eval, out_red)
+  switch (op) {
+    case MDHIP_R_SUM: MD_VMER(RSum);
+    case MDHIP_R_PROD: MD_VMER(RProd);
+    case MDHIP_R_MAX: MD_VMER(RMax);
+    case MDHIP_R_MIN: MD_VMER(RMin);
+  }
+#undef MD_VMER
+  return md_fail(MDHIP_EVALUE, "vm_eval_reduce_cols: reduce op %d is not fused", op);
 }
 
 int mdhip_vm_jit_stats(int64_t stats[2]) {

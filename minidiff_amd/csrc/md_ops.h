@@ -106,6 +106,15 @@ MD_MATH1(ceil, ceilf, ceil)
 MD_MATH1(floor, floorf, floor)
 MD_MATH1(fabs, fabsf, fabs)
 #undef MD_MATH1
+// sin and cos of one argument with ONE argument reduction (device: OCML sincos — the same reduction and
+// polynomials as sinf / cosf, so each result equals the separate call bit for bit; tests/test_lazy_fusion.py)
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)
+MD_HD void md_sincos(float x, float *s, float *c) { sincosf(x, s, c); }
+MD_HD void md_sincos(double x, double *s, double *c) { sincos(x, s, c); }
+#else
+MD_HD void md_sincos(float x, float *s, float *c) { *s = sinf(x); *c = cosf(x); }
+MD_HD void md_sincos(double x, double *s, double *c) { *s = sin(x); *c = cos(x); }
+#endif
 MD_HD float md_fmod(float a, float b) { return fmodf(a, b); }
 MD_HD double md_fmod(double a, double b) { return fmod(a, b); }
 MD_HD float md_pow(float a, float b) { return powf(a, b); }

@@ -282,6 +282,8 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_cols_sweep(const Tacc *__re
   }
 }
 
+#include "md_cols_merge.h"
+
 // ---------------------------------------------------------------- generic ------
 template <class R, class Tacc, class To>
 __global__ void __launch_bounds__(MD_BLOCK) k_reduce_generic(MdRedPlan pl, const void *x, int xdt, To *out) {
@@ -496,7 +498,7 @@ struct HipExec {
         constexpr bool cheap = md_same<R, RSum>::value || md_same<R, RProd>::value ||
                                ((md_same<R, RMax>::value || md_same<R, RMin>::value) && md_same<Tacc, float>::value);
         if (cheap && vec_ok && sweep_mode && n_out == qv * MD_BLOCK * V && (qv == 1 || qv == 2 || qv == 4 || qv == 8) && n_red >= 512) {
-          int64_t nblk = sweep_mode > 1 ? sweep_mode : MD_NUM_CUS;
+          int64_t nblk = sweep_mode > 1 && sweep_mode <= 256 ? sweep_mode : MD_NUM_CUS;  // (the merge pass takes <= 256 partial rows)
           if (nblk > n_red / 6) nblk = n_red / 6;
           const int64_t chunk = ceil_div(n_red, nblk);
           nblk = ceil_div(n_red, chunk);
@@ -514,9 +516,7 @@ struct HipExec {
             default: MD_SWEEP(8); break;
           }
 #undef MD_SWEEP
-          const int64_t bxv2 = ceil_div(n_out, 64 * V);
-          const int64_t chunk2 = ceil_div(nblk, 16) * 16;
-          k_reduce_cols_vec<R, Tacc, To, true><<<dim3((unsigned)bxv2, 1), MD_BLOCK, 0, st>>>((const Tacc *)partial, n_out, nblk, n_out, chunk2, (To *)out->data);
+          k_reduce_cols_merge<R, Tacc, To><<<(unsigned)ceil_div(n_out, 64), 1024, 0, st>>>((const Tacc *)partial, n_out, nblk, (To *)out->data);  // nblk <= 256
           int rc = MD_LAUNCH_CHECK("reduce(cols,sweep)");
           mdhip_free(partial);
           return rc;

@@ -48,7 +48,7 @@ def lazy_enabled() -> bool:
 
 
 # launches issued for pending expressions (tests assert that fusion really happened)
-FUSION_STATS = {"vm_eval": 0, "vm_reduce": 0, "vm_eval_multi": 0}
+FUSION_STATS = {"vm_eval": 0, "vm_reduce": 0, "vm_eval_multi": 0, "vm_eval_reduce_cols": 0, "deferred_cols": 0}
 
 _DTYPE_CODES = {
     np.dtype(np.bool_): _capi.BOOL,
@@ -82,10 +82,11 @@ def _lib() -> _capi.Library:
 class _Buffer:
     """Owner of one allocator block; freed when the last view drops it."""
 
-    __slots__ = ("ptr", "nbytes", "_free", "deps")
+    __slots__ = ("ptr", "nbytes", "_free", "deps", "task", "__weakref__")
 
     def __init__(self, nbytes: int):
         self.deps = None  # {id: weakref} of pending (lazy) arrays that read this block
+        self.task = None  # deferred fill of this block (lazy mode: _ColsTask); run before any access to its bytes
         lib = _lib()
         p = C.c_void_p()
         lib.alloc(builtins_max(int(nbytes), 1), C.byref(p))
@@ -177,7 +178,7 @@ def normalize_axes(axis, ndim) -> tuple:
 
 
 class DeviceArray:
-    __slots__ = ("_buf", "_offset", "shape", "_strides", "dtype", "_code", "_expr", "_cdesc", "__weakref__")
+    __slots__ = ("_buf", "_offset", "shape", "_strides", "dtype", "_code", "_expr", "_cdesc", "_tasks", "__weakref__")
     __array_priority__ = 1000.0
     __hash__ = None
 
@@ -190,6 +191,7 @@ class DeviceArray:
         self._code = code if code >= 0 else dtype_code(dtype)
         self._expr = None  # pending expression (lazy mode); _buf is None until materialised
         self._cdesc = None  # own-shape C descriptor, built once (geometry and block never change)
+        self._tasks = None  # weakrefs to deferred reductions of this pending expression (_ColsTask)
 
     # ---- lazy evaluation -----------------------------------------------------
     @staticmethod
@@ -212,10 +214,45 @@ class DeviceArray:
         prog, keep = _lz.build_program(e, self.shape)
         self._buf = _Buffer(_prod(self.shape) * self.dtype.itemsize)
         self._expr = None
-        if self.size:
-            _lib().vm_eval(prog, self.desc())
-            FUSION_STATS["vm_eval"] += 1
+        try:
+            tasks = self._live_tasks()
+            if self.size:
+                fused = None
+                if tasks:
+                    # a reduce-to-shape of this expression is still owed: evaluate and reduce in ONE pass
+                    t = tasks[0]
+                    res = t.res
+                    t.claim()
+                    try:
+                        _lib().vm_eval_reduce_cols(prog, t.code, self.desc(), res.desc())
+                        FUSION_STATS["vm_eval_reduce_cols"] += 1
+                        fused = t
+                    except ValueError:  # shape not covered by the one-pass kernel
+                        pass
+                if fused is None:
+                    _lib().vm_eval(prog, self.desc())
+                    FUSION_STATS["vm_eval"] += 1
+                for k, t in enumerate(tasks):
+                    if t is not fused:  # from the materialised value (one more read, same result)
+                        r = res if k == 0 else t.res
+                        t.claim()
+                        _lib().reduce(t.code, self.desc(), r.desc(), 1)
+        except BaseException:
+            # the launch did not happen: the array must not look materialised over an unwritten block
+            self._buf, self._expr, self._cdesc = None, e, None
+            raise
         del keep
+
+    def _live_tasks(self):
+        ts, self._tasks = self._tasks, None
+        if not ts:
+            return ()
+        out = []
+        for r in ts:
+            t = r()
+            if t is not None and not t.done and t._buf() is not None:
+                out.append(t)
+        return out
 
     def materialize(self) -> "DeviceArray":
         if self._buf is None:
@@ -260,11 +297,19 @@ class DeviceArray:
         return out
 
     # ---- geometry -----------------------------------------------------------
+    def _block(self) -> _Buffer:
+        """The allocator block with its bytes valid: evaluates a pending expression / runs a deferred fill."""
+        b = self._buf
+        if b is None:
+            self._materialize()
+            b = self._buf
+        if b.task is not None:
+            b.task.run()
+        return b
+
     @property
     def ptr(self) -> int:
-        if self._buf is None:
-            self._materialize()
-        return self._buf.ptr + self._offset * self.dtype.itemsize
+        return self._block().ptr + self._offset * self.dtype.itemsize
 
     @property
     def ndim(self) -> int:
@@ -301,9 +346,7 @@ class DeviceArray:
 
     @property
     def base(self):
-        if self._buf is None:
-            self._materialize()
-        return self._buf
+        return self._block()
 
     @property
     def T(self) -> "DeviceArray":
@@ -316,6 +359,9 @@ class DeviceArray:
 
     def desc(self, shape=None) -> ArrayDesc:
         """C descriptor; with `shape`, broadcast (stride 0) to that shape."""
+        b = self._buf
+        if b is not None and b.task is not None:
+            b.task.run()
         if shape is None or shape == self.shape:
             d = self._cdesc
             if d is None:
@@ -1316,20 +1362,80 @@ def _fused_reduce(code, a, mask, kshape, out_dtype):
     cols = nd == 2 and mask == 1 and a.shape[0] > 1 and a.shape[1] > 1 and a.shape[1] % 4 == 0
     if not (full or cols):
         return None
-    prog, keep = _lz.build_program(e, a.shape)
+    if cols and not full and a.size >= _DEFER_COLS_MIN and a.shape[1] % 1024 == 0 and a.shape[0] >= 512:
+        # reduce-to-shape of an expression that is usually ALSO needed in memory (g * mask feeds the weight-gradient
+        # GEMM and, column-summed, the bias gradient): owe the reduction until the expression is materialised, so that
+        # both cost one pass (mdhip_vm_eval_reduce_cols); if the result is wanted first, it is computed alone
+        res = DeviceArray.empty(kshape, out_dtype)
+        task = _ColsTask(a, code, res)
+        res._buf.task = task
+        ts = a._tasks
+        if ts is None:
+            ts = a._tasks = []
+        ts.append(weakref.ref(task))
+        FUSION_STATS["deferred_cols"] += 1
+        return res
     res = DeviceArray.empty(kshape, out_dtype)
+    if not _reduce_pending(e, a.shape, code, mask, res):
+        return None
+    return res
+
+
+_DEFER_COLS_MIN = 1 << 18
+
+
+def _reduce_pending(e, shape, code, mask, res) -> py_bool:
+    prog, keep = _lz.build_program(e, shape)
+    nd = len(shape)
     shape_like = ArrayDesc()
     shape_like.dtype = e.cdt
     shape_like.ndim = nd
     if nd:
-        shape_like.shape[:nd] = a.shape
+        shape_like.shape[:nd] = shape
     try:
         _lib().vm_reduce(prog, code, shape_like, res.desc(), mask)
     except ValueError:
-        return None
+        return False
     FUSION_STATS["vm_reduce"] += 1
     del keep
-    return res
+    return True
+
+
+class _ColsTask:
+    """A column reduction (axis 0) of a pending 2-D expression whose result block exists but is not filled yet.
+    Owned by the result's block (`_Buffer.task`) and referring back to it weakly (no cycle: dropping the result
+    drops the task and releases the expression); the source array keeps a weak reference too. Runs (a) fused
+    into the source's materialisation, or (b) alone, the moment anything needs the result's bytes."""
+
+    __slots__ = ("src", "code", "_buf", "_kshape", "_dtype", "done", "__weakref__")
+
+    def __init__(self, src, code, res):
+        self.src, self.code, self.done = src, code, False
+        self._buf, self._kshape, self._dtype = weakref.ref(res._buf), res.shape, res.dtype
+
+    @property
+    def res(self):
+        return DeviceArray(self._buf(), 0, self._kshape, _c_strides(self._kshape), self._dtype)
+
+    def claim(self):
+        """Mark as being carried out by the caller (who then fills `res`)."""
+        self.done = True
+        b = self._buf()
+        if b is not None:
+            b.task = None
+        self.src = None
+
+    def run(self):
+        if self.done:
+            return
+        a, res = self.src, self.res
+        self.claim()
+        e = a._expr
+        if e is None:  # (materialised by a path that did not see the task)
+            _lib().reduce(self.code, a.desc(), res.desc(), 1)
+        elif not _reduce_pending(e, a.shape, self.code, 1, res):
+            a._materialize()
+            _lib().reduce(self.code, a.desc(), res.desc(), 1)
 
 
 def _sum_dtype(a_dtype, dtype):
@@ -1949,7 +2055,7 @@ def _build_plan(a: DeviceArray, entries):
         lead = nb - ix.ndim
         for j, (m, st) in enumerate(zip(ix.shape, ix._strides)):
             plan.idx_strides[k][b0 + lead + j] = 0 if (m == 1 and bshape[lead + j] != 1) else st
-    base_ptr = a._buf.ptr + off * a.dtype.itemsize
+    base_ptr = a._block().ptr + off * a.dtype.itemsize
     return plan, tuple(out_shape), base_ptr, keep
 
 
@@ -2129,7 +2235,7 @@ def materialize_many(arrays):
             pending.append(a)
     groups = {}
     for a in pending:
-        if a.size and a.dtype in _FLOAT_DT and _FLOAT_DT[a.dtype] == a._expr.cdt:
+        if a.size and a.dtype in _FLOAT_DT and _FLOAT_DT[a.dtype] == a._expr.cdt and not a._tasks:  # (owed reductions ride on a single evaluation)
             groups.setdefault((a.shape, a._expr.cdt), []).append(a)
     for group in groups.values():
         while len(group) >= 2:
@@ -2147,6 +2253,7 @@ def materialize_many(arrays):
             progs = (_capi.VmProgram * len(batch))()
             outs = (_capi.ArrayDesc * len(batch))()
             keep = []
+            saved = [a._expr for a in batch]
             for k, a in enumerate(batch):
                 prog, kp = _lz.build_program(a._expr, a.shape)
                 progs[k] = prog
@@ -2154,11 +2261,19 @@ def materialize_many(arrays):
                 a._buf = _Buffer(_prod(a.shape) * a.dtype.itemsize)
                 a._expr = None
                 outs[k] = a.desc()
-            _lib().vm_eval_multi(progs, outs, len(batch))
+            try:
+                _lib().vm_eval_multi(progs, outs, len(batch))
+            except BaseException:
+                for a, e in zip(batch, saved):  # nothing was written: stay pending
+                    a._buf, a._expr, a._cdesc = None, e, None
+                raise
             FUSION_STATS["vm_eval_multi"] += 1
             del keep
     for a in pending:
         a.materialize()
+    for a in arrays:  # results whose fill is still owed (deferred reductions)
+        if isinstance(a, DeviceArray) and a._buf is not None and a._buf.task is not None:
+            a._buf.task.run()
     return arrays
 
 

@@ -382,6 +382,18 @@ int mdhip_vm_eval_multi(const mdhip_vm_program *progs, const mdhip_array *outs, 
 int mdhip_vm_jit_probe_multi(const mdhip_vm_program *, int, char *, size_t) {
   return md_fail(MDHIP_ERUNTIME, "the CPU test double has no run-time compiler");
 }
+// one-pass eval + column reduce: here simply the two plain loops, same results
+int mdhip_vm_eval_reduce_cols(const mdhip_vm_program *pr, int op, const mdhip_array *out_eval, const mdhip_array *out_red) {
+  MD_TRY(md_vm_check(pr));
+  MD_TRY(md_check_array(out_eval, "vm out"));
+  MD_TRY(md_check_array(out_red, "vm out"));
+  if (out_eval->dtype != pr->compute_dtype || out_red->dtype != pr->compute_dtype)
+    return md_fail(MDHIP_ETYPE, "vm_eval_reduce_cols: both outputs must have the compute dtype");
+  if (out_eval->ndim != 2 || out_eval->shape[0] < 2 || (out_eval->shape[1] & 3))
+    return md_fail(MDHIP_EVALUE, "vm_eval_reduce_cols: shape not covered by the one-pass kernel");
+  MD_TRY(mdhip_vm_eval(pr, out_eval));
+  return mdhip_vm_reduce(pr, op, out_eval, out_red, 1u);
+}
 
 // data-parallel entry points: the double has no collective; world size 1 only.
 int mdhip_comm_get_unique_id(uint8_t uid[MDHIP_UID_BYTES]) { memset(uid, 0, MDHIP_UID_BYTES); return MDHIP_OK; }

@@ -11,7 +11,7 @@ from minidiff_amd import _capi, ndarray as nd  # noqa: E402
 
 
 def main():
-    lib = _capi.load()
+    lib = _capi.use_library(os.environ['MDHIP_AB_LIB']) if os.environ.get('MDHIP_AB_LIB') else _capi.load()
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
     rng = np.random.default_rng(0)
     x = nd.asarray(rng.standard_normal(N, dtype=np.float32))

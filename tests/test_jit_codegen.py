@@ -41,6 +41,12 @@ def _programs(nd):
         progs.append((name + "/const-left", getattr(nd, name)(2.0, nd.sin(x))))
     progs.append(("where", nd.where(nd.greater(x, 0), nd.multiply(x, m), 0.25)))
     progs.append(("f64+int leaf", nd.add(nd.exp(xd), xi)))
+    # every leaf read mode, with the hoisted sin / cos on each of them: unit stride (x), row-invariant (b), column
+    # broadcast (col), one device element behind a stride-0 view (seed)
+    col = nd.asarray(rng.standard_normal((8, 1)).astype(np.float32))
+    seed = nd.broadcast_to(nd.asarray(np.float32(0.5)), (8, 16))
+    progs.append(("leaf modes", nd.add(nd.add(nd.multiply(nd.sin(x), nd.cos(x)), nd.multiply(nd.sin(b), nd.cos(col))),
+                                       nd.multiply(nd.multiply(nd.sin(seed), nd.cos(seed)), nd.sin(col)))))
     progs.append(("cfg3 x.grad", nd.multiply(nd.multiply(nd.multiply(nd.multiply(
         nd.broadcast_to(nd.asarray(np.float32(1)), (8, 16)), 2), nd.power(nd.multiply(nd.sin(x), y), 1)), y), nd.cos(x))))
     out = []
@@ -63,12 +69,17 @@ def test_generated_kernels_compile(lib, on_gpu, product):
     for name, prog, keep, is_bool in progs:
         plib.vm_jit_probe(prog, 0, 0, int(is_bool), log, len(log))
         n += 1
-        if not is_bool and name in ("sin", "multiply", "where", "f64+int leaf", "cfg3 x.grad"):   # epilogues: a subset keeps this quick
+        if not is_bool and name in ("sin", "multiply", "where", "f64+int leaf", "cfg3 x.grad", "leaf modes"):   # epilogues: a subset keeps this quick
             for rop in (_capi.R_SUM, _capi.R_PROD, _capi.R_MAX, _capi.R_MIN):
                 plib.vm_jit_probe(prog, 1, rop, 0, log, len(log))
                 plib.vm_jit_probe(prog, 2, rop, 0, log, len(log))
                 n += 2
-    assert n > 90
+            # sweep-style column reduce, without / with the evaluated value stored (mdhip_vm_eval_reduce_cols)
+            plib.vm_jit_probe(prog, 3, _capi.R_SUM, 0, log, len(log))
+            plib.vm_jit_probe(prog, 4, _capi.R_SUM, 0, log, len(log))
+            plib.vm_jit_probe(prog, 4, _capi.R_MAX, 0, log, len(log))
+            n += 3
+    assert n > 110
 
 
 def test_generated_multi_output_kernel_compiles(lib, on_gpu, product):

@@ -201,3 +201,120 @@ def test_interpreter_only_gpu(on_gpu):
                         os.path.join(here, "test_golden_device.py"), "-m", "gpu", "-q", "--no-header", "-p", "no:cacheprovider",
                         "-k", "not interpreter_only"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+# ---- deferred reduce-to-shape: the column sum of a pending expression is owed until the expression is
+# ---- materialised (one pass for both: mdhip_vm_eval_reduce_cols), or computed alone if it is wanted first
+def _deferred_cols(nd, on_gpu, want_gpu):
+    if want_gpu != on_gpu:
+        pytest.skip("other twin")
+    rng = np.random.default_rng(5)
+    R, C = 640, 1024
+    z = rng.standard_normal((R, C)).astype(np.float32)
+    b = rng.standard_normal((C,)).astype(np.float32)
+    dz, db = nd.asarray(z), nd.asarray(b)
+    seed = nd.broadcast_to(nd.asarray(np.float32(1.5)), (R, C))
+    exp_g = np.float32(1.5) * ((z + b) > 0)
+
+    def pending():
+        return nd.multiply(seed, nd.greater(nd.add(dz, db), 0))
+
+    # (1) expression materialised first: ONE pass gives both
+    s0 = dict(nd.FUSION_STATS)
+    g = pending()
+    cs = nd.sum(g, axis=(0,), keepdims=True)
+    assert nd.FUSION_STATS["deferred_cols"] - s0["deferred_cols"] == 1
+    assert cs.shape == (1, C) and g._buf is None
+    flat = nd.reshape(cs, (C,))                      # a view of an unfilled result must not force it
+    assert g._buf is None and nd.FUSION_STATS["vm_reduce"] == s0["vm_reduce"]
+    gm = nd.matmul(nd.transpose(dz), g)              # needs g in memory -> eval + column sum in one kernel
+    import os
+    one_pass = nd.FUSION_STATS["vm_eval_reduce_cols"] - s0["vm_eval_reduce_cols"]
+    if os.environ.get("MDHIP_JIT") == "0":   # interpreter only: no one-pass kernel, the two passes run separately
+        assert one_pass == 0 and nd.FUSION_STATS["vm_eval"] - s0["vm_eval"] == 1
+    else:
+        assert one_pass == 1 and nd.FUSION_STATS["vm_eval"] == s0["vm_eval"]
+    assert nd.FUSION_STATS["vm_reduce"] == s0["vm_reduce"]
+    assert np.array_equal(g.get(), exp_g)
+    _close(flat.get(), exp_g.sum(axis=0, dtype=np.float64), 1e-6)
+    _close(gm.get(), z.T.astype(np.float64) @ exp_g, 1e-5)
+
+    # (2) the reduction is wanted first: computed alone, the expression stays pending
+    s0 = dict(nd.FUSION_STATS)
+    g = pending()
+    cs = nd.sum(g, axis=0)
+    got = cs.get()
+    assert nd.FUSION_STATS["vm_reduce"] - s0["vm_reduce"] == 1 and g._buf is None
+    _close(got, exp_g.sum(axis=0, dtype=np.float64), 1e-6)
+    assert np.array_equal(g.get(), exp_g)
+    assert nd.FUSION_STATS["vm_eval_reduce_cols"] == s0["vm_eval_reduce_cols"]
+
+    # (3) result dropped before anything ran: nothing owed any more
+    s0 = dict(nd.FUSION_STATS)
+    g = pending()
+    cs = nd.sum(g, axis=0)
+    del cs
+    assert np.array_equal(g.get(), exp_g)
+    assert nd.FUSION_STATS["vm_eval"] - s0["vm_eval"] == 1 and nd.FUSION_STATS["vm_eval_reduce_cols"] == s0["vm_eval_reduce_cols"]
+
+    # (4) a leaf is overwritten in place while the reduction is owed: values are those at call time
+    dz2 = nd.asarray(z.copy())
+    g = nd.multiply(seed, nd.greater(nd.add(dz2, db), 0))
+    cs = nd.sum(g, axis=0)
+    dz2 *= -1.0
+    _close(cs.get(), exp_g.sum(axis=0, dtype=np.float64), 1e-6)
+    assert np.array_equal(g.get(), exp_g)
+
+    # (5) two reductions owed on one expression (sum and max), then an in-place update of one result
+    g = pending()
+    cs, cm = nd.sum(g, axis=0), nd.max(g, axis=0)
+    cs += 1.0
+    _close(cs.get(), exp_g.sum(axis=0, dtype=np.float64) + 1.0, 1e-6)
+    nd.materialize(g)
+    assert np.array_equal(cm.get(), exp_g.max(axis=0))
+    # (6) end-of-sweep flush (workloads._finish -> materialize_many) fills results still owed
+    g = pending()
+    cs = nd.sum(g, axis=0)
+    nd.materialize_many([cs])
+    assert cs._buf.task is None
+    _close(cs.get(), exp_g.sum(axis=0, dtype=np.float64), 1e-6)
+
+
+def test_deferred_cols_cpu(lazy_nd, on_gpu): _deferred_cols(lazy_nd, on_gpu, False)
+@gpu
+def test_deferred_cols_gpu(lazy_nd, on_gpu): _deferred_cols(lazy_nd, on_gpu, True)
+
+
+def _sincos_hoist(nd, on_gpu, want_gpu):
+    """sin(x) and cos(x) of one leaf inside a fused program come from ONE sincos (fusion_jit.inc):
+    the values must equal the eager kernels' bit for bit, for small and for huge arguments."""
+    if want_gpu != on_gpu:
+        pytest.skip("other twin")
+    rng = np.random.default_rng(9)
+    n = 1 << 19
+    x = (rng.standard_normal(n) * np.repeat([1.0, 50.0, 1e4, 1e9], n // 4)).astype(np.float32)
+    y = rng.standard_normal(n).astype(np.float32)
+    prev = nd.set_lazy(False)
+    dx, dy = nd.asarray(x), nd.asarray(y)
+    es, ec = nd.sin(dx).get(), nd.cos(dx).get()
+    eprod = nd.multiply(nd.multiply(nd.sin(dx), dy), nd.cos(dx)).get()
+    nd.set_lazy(True)
+    try:
+        a = nd.multiply(nd.sin(dx), 1.0)
+        b = nd.multiply(nd.cos(dx), 1.0)
+        nd.materialize_many([a, b])          # multi-output program: sin and cos of the same leaf
+        assert np.array_equal(a.get(), es) and np.array_equal(b.get(), ec)
+        p = nd.multiply(nd.multiply(nd.sin(dx), dy), nd.cos(dx))
+        assert np.array_equal(p.get(), eprod)
+        for dt in (np.float64,):
+            x64 = x.astype(dt)
+            d64 = nd.asarray(x64)
+            q = nd.add(nd.sin(d64), nd.cos(d64))
+            _close(q.get(), np.sin(x64) + np.cos(x64), 1e-15)
+    finally:
+        nd.set_lazy(prev)
+
+
+def test_sincos_hoist_cpu(lazy_nd, on_gpu): _sincos_hoist(lazy_nd, on_gpu, False)
+@gpu
+def test_sincos_hoist_gpu(lazy_nd, on_gpu): _sincos_hoist(lazy_nd, on_gpu, True)

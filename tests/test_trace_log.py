@@ -25,7 +25,7 @@ print(np.asarray(c).shape)
 def test_call_log_lists_entry_points_with_shapes(tmp_path, lib, on_gpu):
     from conftest import HOST_DOUBLE
     log = tmp_path / "calls.jsonl"
-    env = dict(os.environ, MDHIP_TRACE=str(log))
+    env = dict(os.environ, MDHIP_TRACE=str(log), MDHIP_LAZY="0")  # the eager entry points are what the log is checked for
     p = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT, "double": "" if on_gpu else HOST_DOUBLE}],
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
