@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — forward+backward passes/sec of the minidiff hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg3|cfg4|cfg5]
+    python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg3|cfg4|cfg5] [--lazy] [--graph]
 
 Metric (BASELINE.json): forward+backward passes/sec on the 4096x4096 fp32 matmul
-graph. Default workload = configs[1] (cfg2): C = A @ B; C.backward() — 3 GEMMs
-(NN, NT, TN), 412,316,860,416 FLOP per sweep, inputs resident in HBM.
-With N > 1 the sweep is batch-sharded: every rank owns its own 4096-row batch
-block A_r (rows are independent), B is the replicated parameter, and B.grad is
-summed with ONE RCCL all-reduce (67,108,864 B) per sweep; per-GPU work is fixed
-("weak" scaling) and `value` counts the sweeps all ranks completed per second.
-`--workload cfg4` runs BASELINE's MLP config instead (global batch 8192 split
-over the ranks, bucketed [W.grad || b.grad] all-reduce).
+graph. At N = 1 the headline workload is configs[1] (cfg2): C = A @ B;
+C.backward() — 3 GEMMs (NN, NT, TN), 412,316,860,416 FLOP per sweep, inputs
+resident in HBM. After the headline's timed region the same process runs the other
+BASELINE configs (cfg3 eager / lazy, cfg4 eager / lazy, cfg5) and reports them
+under "secondary" — value, ms per sweep and the roofline of their dominant
+kernels from HIP events — so that one driver run carries the HBM-bound numbers
+too (`--no-secondary` skips them).
+
+With N > 1 (one rank per GPU, launched by torch.distributed.run) the default
+workload is BASELINE's configs[3] (cfg4): the global batch of 8192 rows is split
+over the ranks (strong scaling), [W.grad || b.grad] is summed by RCCL all-reduce
+in row panels that leave while the weight-gradient GEMM is still running, and
+`tensors_per_s` = 8192 x sweeps/s. `--workload cfg2` at N > 1 is the weak-scaling
+variant (every rank owns its own 4096-row block A_r; B.grad all-reduced); it is
+also run after the headline and reported under "secondary".
 
 One JSON line on stdout (rank 0). `roofline` prices the dominant kernel from HIP
 events recorded on the library's stream inside the timed region; `cpu_baseline`
@@ -20,6 +27,7 @@ times the NumPy oracle (the reference's arithmetic) on this host's cores.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -32,6 +40,7 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix, dense
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+MIB = 1 << 20
 
 
 def parse():
@@ -39,9 +48,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="default: cfg2 on one GPU (BASELINE's headline), cfg4 on several (BASELINE's batch-sharded config)")
     ap.add_argument("--size", type=int, default=0, help="override the problem size (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="only the headline workload")
     ap.add_argument("--lazy", action="store_true",
                     help="opt-in lazy fusion of elementwise chains (minidiff_amd/lazy.py); default is eager")
     ap.add_argument("--graph", action="store_true",
@@ -53,7 +64,7 @@ def parse():
 class KernelTimer:
     """Brackets chosen backend calls with HIP events on libmdhip's stream."""
 
-    def __init__(self, lib, capacity=4096):
+    def __init__(self, lib, capacity=8192):
         import ctypes as C
         self.C, self.lib = C, lib
         self.pool, self.used, self.enabled = [], [], False
@@ -67,6 +78,7 @@ class KernelTimer:
         return ev
 
     def wrap(self, fn, tag):
+        """`tag`: a name, or a function of the call's arguments returning one."""
         def timed(*a, **kw):
             if not self.enabled or len(self.used) >= self.capacity:
                 return fn(*a, **kw)
@@ -74,9 +86,23 @@ class KernelTimer:
             self.lib.event_record(e0)
             out = fn(*a, **kw)
             self.lib.event_record(e1)
-            self.used.append((tag, e0, e1))
+            self.used.append((tag(*a, **kw) if callable(tag) else tag, e0, e1))
             return out
         return timed
+
+    def empty_bracket_ms(self, reps=20):
+        """Elapsed time of a bracket with NOTHING inside: what the two event markers themselves add to every
+        bracketed duration (a few microseconds: matters for the 25-50 us streaming kernels, not for the GEMMs)."""
+        ms, tot = self.C.c_float(), 0.0
+        for _ in range(reps):
+            e0, e1 = self._event(), self._event()
+            self.lib.event_record(e0)
+            self.lib.event_record(e1)
+            self.lib.sync()
+            self.lib.event_elapsed_ms(e0, e1, self.C.byref(ms))
+            tot += float(ms.value)
+            self.pool += [e0, e1]
+        return tot / reps
 
     def collect(self):
         ms = self.C.c_float()
@@ -147,6 +173,116 @@ def cpu_baseline(workload, size):
     }
 
 
+PREROLL = {"cfg2": 12, "cfg3": 20, "cfg4": 10, "cfg5": 40}
+DEFAULT_SIZE = {"cfg2": 4096, "cfg3": 100_000_000, "cfg4": 8192, "cfg5": 2048}
+
+
+def describe(workload, n, lazy):
+    mode = " [lazy fusion]" if lazy else ""
+    return {
+        "cfg2": f"cfg2: C=A@B ({n}x{n} fp32), C.backward(); 3 GEMMs NN/NT/TN; per-rank batch block, B.grad all-reduced",
+        "cfg3": f"cfg3: sum((sin(x)*y)**2).backward(), N={n} fp32" + (mode if lazy else " [eager: 11 kernels]"),
+        "cfg4": f"cfg4: sum(relu(X@W+b)).backward(), global batch {n} x 4096 -> 4096, row-sharded" + mode,
+        "cfg5": f"cfg5: second order on {n}x{n} matmul, 5 GEMMs",
+    }[workload]
+
+
+def _mean(v):
+    return sum(v) / len(v) if v else None
+
+
+def _hbm(kernel, nbytes, ms, **extra):
+    ach = nbytes / (ms * 1e-3) / 1e9
+    d = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+         "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms}
+    d.update(extra)
+    return d
+
+
+def rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc):
+    """-> (roofline of the dominant kernel, extra per-kernel detail) from the HIP-event durations of the timed region."""
+    detail = {k: {"launches": len(v), "avg_ms": _mean(v)} for k, v in sorted(kernel_ms.items())}
+    if workload in ("cfg2", "cfg5") or (workload == "cfg4"):
+        durs = [d for k, v in kernel_ms.items() if k.startswith("matmul") for d in v]
+        n_gemm = {"cfg2": 3, "cfg4": 2, "cfg5": 5}[workload]
+        flop_per_launch = state["flops"] / n_gemm
+        main = None
+        # in lazy mode the weight-gradient matmul call also launches the fused pass that produces its operand:
+        # price the GEMM on the calls that contain nothing else
+        if workload == "cfg4" and lazy:
+            durs = kernel_ms.get("matmul_nn", [])
+        elif workload == "cfg4":
+            durs = kernel_ms.get("matmul_nn", []) + kernel_ms.get("matmul_tn", [])
+        if durs:
+            avg = _mean(durs)
+            ach = flop_per_launch / (avg * 1e-3) / 1e12
+            committed = pmc_mean(pmc, "k_gemm_f32_mfma") if workload == "cfg2" and not size else None
+            main = {"bound": "mfma", "kernel": "k_gemm_f32_mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
+                    "traffic": None,  # not measured in this run (PMC passes need the profiler)
+                    "traffic_committed": committed, "traffic_committed_source": pmc.get("_source") if committed else None,
+                    "launches": len(durs), "avg_launch_ms": avg, "flop_per_launch": flop_per_launch,
+                    "algorithmic_bytes_per_launch": 3 * 4 * (size or 4096) ** 2 if workload == "cfg2" else None}
+        if workload == "cfg4":
+            rows, cols = state["rows"], 4096
+            e = rows * cols
+            tail = {}
+            if not lazy:
+                # SURVEY 8d byte counts per call as issued by the untouched tape (stride-0 / scalar operands = 0)
+                for tag, name, nbytes in (("add", "bias add", 8 * e + 4 * cols), ("greater", "z > 0 -> bool", 5 * e),
+                                          ("where", "where(mask, z, 0)", 9 * e), ("sum_all", "sum (loss)", 4 * e),
+                                          ("multiply", "mask product g*mask (f32 x bool)", 5 * e),
+                                          ("sum_cols", "column sum (bias gradient, reduce-to-shape)", 4 * e + 4 * cols)):
+                    if kernel_ms.get(tag):
+                        tail[tag] = _hbm(name, nbytes, _mean(kernel_ms[tag]))
+                if "multiply" in tail and "sum_cols" in tail:
+                    ms = tail["multiply"]["avg_launch_ms"] + tail["sum_cols"]["avg_launch_ms"]
+                    tail["backward_pair"] = _hbm("elementwise + reduce-to-shape backward: mask product, then column sum (2 + 2 launches)",
+                                                 9 * e + 4 * cols, ms, note="north_star's >= 60 % HBM target is on this pair")
+            else:
+                if kernel_ms.get("sum_all"):
+                    tail["sum_all"] = _hbm("k_fused_redall: loss = sum(where(X@W+b > 0, X@W+b, 0)) in one pass (+ finish)", 4 * e + 4 * cols,
+                                           _mean(kernel_ms["sum_all"]))
+                if kernel_ms.get("materialize"):
+                    tail["backward_pair"] = _hbm("k_fused_evalcols: g*mask written AND column-summed in one pass (+ merge)", 8 * e + 8 * cols,
+                                                 _mean(kernel_ms["materialize"]),
+                                                 eager_algorithmic_bytes=9 * e + 4 * cols,
+                                                 note="fused bytes: X@W read once, g*mask written once; the eager figure is not mixed in")
+            detail["hbm_tail"] = tail
+        return main, detail
+    n = state["rows"]
+    if lazy:
+        # fused: one reduce pass over (x, y) for the loss (8N), one two-output pass for both gradients (reads x, y
+        # once, writes x.grad and y.grad: 16N) = SURVEY 8d's fused lower bound
+        fused_bytes = 24 * n
+        ach = fused_bytes / (ms_per_step * 1e-3) / 1e9
+        main = {"bound": "hbm", "kernel": "k_fused_redall + k_fused_eval2 (run-time specialised), whole sweep",
+                "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                "fused_algorithmic_bytes_per_sweep": fused_bytes, "eager_algorithmic_bytes_per_sweep": state["bytes"],
+                "note": "achieved = fused bytes / whole-sweep wall time (3 launches incl. the reduction's finish); the eager figure (100N bytes) is not mixed in"}
+        k = {}
+        if kernel_ms.get("sum_all"):
+            k["loss_pass"] = _hbm("k_fused_redall: sum((sin(x)*y)**2), reads x and y (+ finish)", 8 * n, _mean(kernel_ms["sum_all"]))
+        if kernel_ms.get("materialize_many"):
+            k["gradient_pass"] = _hbm("k_fused_eval2: x.grad and y.grad in one pass, one sincos per element", 16 * n, _mean(kernel_ms["materialize_many"]))
+        detail["fused_kernels"] = k
+        return main, detail
+    # dominant kernel of the eager chain: the f32 x f32 multiply (5 of the 11 launches per sweep: read 2 x 4N, write 4N)
+    durs = kernel_ms.get("multiply", [])
+    main = None
+    if durs:
+        avg = _mean(durs)
+        tot_ms = sum(sum(v) for v in kernel_ms.values())
+        steps = len(kernel_ms.get("sin", [])) or 1
+        committed = pmc_mean(pmc, "k_binary_fast<BMul, float, float, float, float") if not size else None
+        main = _hbm("k_ew_fast<BinaryBody<BMul,f32,f32>> (multiply, both operands streamed)", 12 * n, avg, launches=len(durs),
+                    traffic_committed=committed, traffic_committed_source=pmc.get("_source") if committed else None,
+                    whole_sweep={"algorithmic_bytes": state["bytes"], "kernel_ms": tot_ms / steps,
+                                 "GB/s": state["bytes"] * steps / (tot_ms * 1e-3) / 1e9,
+                                 "frac": state["bytes"] * steps / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+    return main, detail
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -164,6 +300,8 @@ def main():
     # rehearse it on a one-GPU box
     force_dist = os.environ.get("MDHIP_BENCH_FORCE_DIST") == "1"
     use_dist = world > 1 or force_dist
+    if args.workload is None:
+        args.workload = "cfg4" if use_dist else "cfg2"
     dist = torch = None
     if use_dist:
         import torch
@@ -175,219 +313,251 @@ def main():
             torch.cuda.set_device(local_rank)
 
     from minidiff_amd import _capi, workloads, dp
+    from minidiff_amd import ndarray as nd
     from minidiff_amd.hip_backend import HipBackendTable
     from minidiff_amd.tape import build_engine
 
     lib = _capi.load()  # ImportError if the HIP extension is missing: no fallback
     timer = KernelTimer(lib)
-    if args.lazy:
-        from minidiff_amd import ndarray as _nd
-        _nd.set_lazy(True)
 
-    # instrumented copy of the table: same functions, dominant kernels bracketed by events
-    dominant = {"cfg2": ["matmul"], "cfg4": ["matmul"], "cfg5": ["matmul"],
-                "cfg3": ["sin", "cos", "multiply", "power", "sum"]}[args.workload]
+    # instrumented copy of the table: same functions, the kernels of the BASELINE graphs bracketed by events
+    def is_arr(x):
+        return isinstance(x, nd.DeviceArray)
+
+    def tag_matmul(a, b, *_, **__):
+        if is_arr(a) and is_arr(b) and a.ndim == 2 and b.ndim == 2:
+            at, bt = a._strides[-1] != 1, b._strides[-1] != 1
+            return "matmul_" + ("t" if at else "n") + ("t" if bt else "n")
+        return "matmul"
+
+    tags = {
+        "matmul": tag_matmul,
+        # (cfg3: the five full-array products vs the scaled stride-0 seed; cfg4: the one mask product)
+        "multiply": lambda a, b, *_, **__: "multiply" if is_arr(a) and is_arr(b) else "multiply_scalar",
+        "sum": lambda a, axis=None, *_, **__: "sum_all" if axis is None or axis == () else "sum_cols",
+        "sin": "sin", "cos": "cos", "power": "power", "add": "add", "greater": "greater", "where": "where",
+    }
     ns = {k: v for k, v in vars(HipBackendTable).items() if not k.startswith("__")}
-    for name in dominant:
-        ns[name] = staticmethod(timer.wrap(getattr(HipBackendTable, name), name))
+    for name, tag in tags.items():
+        ns[name] = staticmethod(timer.wrap(getattr(HipBackendTable, name), tag))
+    ns["_materialize_many"] = staticmethod(timer.wrap(nd.materialize_many, "materialize_many"))
     Table = type("HipBackendTableTimed", (), ns)
     md = build_engine(Table, "hip")
+    # lazy mode launches the fused pass of a pending operand when something needs it in memory
+    _plain_materialize = nd.DeviceArray._materialize
+    nd.DeviceArray._materialize = timer.wrap(_plain_materialize, "materialize")
 
-    kw = {}
-    if args.workload == "cfg2":
-        kw = {"rank": rank}
-        if args.size:
-            kw["n"] = args.size
-    elif args.workload == "cfg4":
-        kw = {"rank": rank, "world": world}
-        if args.size:
-            kw["batch"] = args.size
-    elif args.size:
-        kw = {"n": args.size}
-    state, step = workloads.MAKERS[args.workload](md, **kw)
-
-    comm = None
-    comm_kind = "none"
-    if use_dist and args.workload in ("cfg2", "cfg4"):
-        if args.comm == "rccl":
-            err = None
-            try:
-                comm = dp.RcclComm(rank, world, dist)
-            except Exception as e:  # communicator could not be built on this rank
-                err = e
-            # every rank must take the same path: agree over the gloo control plane
-            flags = [None] * world
-            dist.all_gather_object(flags, err is None)
-            if all(flags):
-                comm_kind = "rccl-direct"
-            else:
-                if comm is not None:
-                    comm.close()
-                    comm = None
-                print(f"[rank {rank}] direct RCCL communicator unavailable ({err or 'failed on another rank'}); "
-                      "using torch.distributed nccl", file=sys.stderr)
-        if comm is None:  # same data path through torch's RCCL
-            comm = dp.TorchComm(rank, world, dist, torch)
-            comm_kind = "rccl-torch"
-    sync = dp.GradSync(md, state["params"] if args.workload == "cfg4" else state["params"][:1], comm, force=force_dist,
-                       overlap=os.environ.get("MDHIP_DP_OVERLAP", "1") != "0")
-
-    def sweep():
-        step()
-        sync()
+    pmc = load_pmc_traffic()
 
     def barrier():
         lib.sync()
         if use_dist:
             dist.barrier()
 
-    # untimed pre-roll before the W warm-up sweeps: the first ~15 ms of work after process start run
-    # at ramping clocks and grow the allocator cache (W <= 2 alone measured 7 % low on cfg2)
-    # (a fixed count, not a time: every rank must issue the same number of collectives)
-    preroll = {"cfg2": 12, "cfg3": 20, "cfg4": 10, "cfg5": 40}[args.workload]
-    for _ in range(preroll):
-        sweep()
-    lib.sync()
+    def make_comm(workload):
+        comm, kind = None, "none"
+        if use_dist and workload in ("cfg2", "cfg4"):
+            if args.comm == "rccl":
+                err = None
+                try:
+                    comm = dp.RcclComm(rank, world, dist)
+                except Exception as e:  # communicator could not be built (on this or another rank: RcclComm fails on all together)
+                    err = e
+                # every rank must take the same path: agree over the gloo control plane
+                flags = [None] * world
+                dist.all_gather_object(flags, err is None)
+                if all(flags):
+                    kind = "rccl-direct"
+                else:
+                    if comm is not None:
+                        comm.close()
+                        comm = None
+                    print(f"[rank {rank}] direct RCCL communicator unavailable ({err or 'failed on another rank'}); "
+                          "using torch.distributed nccl", file=sys.stderr)
+            if comm is None:  # same data path through torch's RCCL
+                comm = dp.TorchComm(rank, world, dist, torch)
+                kind = "rccl-torch"
+        return comm, kind
 
-    captured = None
-    if args.graph:
-        if use_dist:
-            raise SystemExit("--graph is a single-GPU mode (the gradient all-reduce is not captured)")
-        # single kernels cannot be bracketed inside a replay: the per-kernel durations the roofline
-        # needs come from the (eager, identical) warm-up sweeps instead
-        sweep()  # cold start (code object load, allocator growth) stays out of the kernel averages
-        timer.enabled = True
-        for _ in range(max(args.warmup, 1)):
+    def run(workload, lazy, steps, warmup, graph=False, size=0, keep=None):
+        """One workload: pre-roll, W warm-up sweeps, K timed sweeps between barriers, max over ranks.
+        `keep`: dict carrying (state, step) between the eager and the lazy run of one workload."""
+        prev_lazy = nd.set_lazy(bool(lazy))
+        kw = {}
+        if workload == "cfg2":
+            kw = {"rank": rank}
+            if size:
+                kw["n"] = size
+        elif workload == "cfg4":
+            kw = {"rank": rank, "world": world}
+            if size:
+                kw["batch"] = size
+        elif size:
+            kw = {"n": size}
+        if keep is not None and "state" in keep:
+            state, step = keep["state"], keep["step"]
+        else:
+            state, step = workloads.MAKERS[workload](md, **kw)
+            if keep is not None:
+                keep["state"], keep["step"] = state, step
+        comm, comm_kind = make_comm(workload)
+        sync = dp.GradSync(md, state["params"] if workload == "cfg4" else state["params"][:1], comm, force=force_dist,
+                           overlap=os.environ.get("MDHIP_DP_OVERLAP", "1") != "0")
+
+        def sweep():
+            step()
+            sync()
+
+        # untimed pre-roll before the W warm-up sweeps: the first ~15 ms of work after process start run
+        # at ramping clocks and grow the allocator cache (W <= 2 alone measured 7 % low on cfg2)
+        # (a fixed count, not a time: every rank must issue the same number of collectives)
+        preroll = PREROLL[workload]
+        for _ in range(preroll):
             sweep()
         lib.sync()
+        captured = None
+        if graph:
+            if use_dist:
+                raise SystemExit("--graph is a single-GPU mode (the gradient all-reduce is not captured)")
+            # single kernels cannot be bracketed inside a replay: the per-kernel durations the roofline
+            # needs come from the (eager, identical) warm-up sweeps instead
+            sweep()  # cold start (code object load, allocator growth) stays out of the kernel averages
+            timer.enabled = True
+            for _ in range(max(warmup, 1)):
+                sweep()
+            lib.sync()
+            timer.enabled = False
+            from minidiff_amd.graph import CapturedSweep
+            captured = CapturedSweep(step, warmup=0)
+            captured.replay()
+            run_one = captured.replay
+        else:
+            for _ in range(warmup):
+                sweep()
+            run_one = sweep
+        barrier()
+        timer.enabled = not graph
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run_one()
+        lib.sync()
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
         timer.enabled = False
-        from minidiff_amd.graph import CapturedSweep
-        captured = CapturedSweep(step, warmup=0)
-        captured.replay()
-        run_one = captured.replay
-    else:
-        for _ in range(args.warmup):
-            sweep()
-        run_one = sweep
-    barrier()
-    timer.enabled = not args.graph
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_one()
-    lib.sync()
-    if torch is not None and torch.cuda.is_available():
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    timer.enabled = False
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            dist.barrier()
+        kernel_ms = timer.collect()
+        ms_per_step = elapsed / steps * 1e3
 
-    kernel_ms = timer.collect()
-    ms_per_step = elapsed / args.steps * 1e3
-
-    # the collective alone (un-overlapped, outside the timed region): time and bus bandwidth
-    allreduce_ms = busbw = None
-    if comm is not None and sync.active:
-        import ctypes as C
-        grads = [p.grad for p in sync.params]
-        buf = sync.bucket if sync.bucket is not None else grads[0]._data
-        e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
-        lib.event_create(C.byref(e0)); lib.event_create(C.byref(e1))
-        reps = 5
-        comm.allreduce_sum_(buf)
-        barrier()
-        lib.event_record(e0)
-        for _ in range(reps):
+        # SURVEY 8e: the collective alone (un-overlapped, outside the timed region): time and bus bandwidth
+        allreduce_ms = busbw = None
+        if comm is not None and sync.active:
+            import ctypes as C
+            grads = [p.grad for p in sync.params]
+            buf = sync.bucket if sync.bucket is not None else grads[0]._data
+            e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+            lib.event_create(C.byref(e0)); lib.event_create(C.byref(e1))
+            reps = 5
             comm.allreduce_sum_(buf)
-        lib.event_record(e1)
-        lib.sync()
-        if comm_kind == "rccl-direct":
-            lib.event_elapsed_ms(e0, e1, C.byref(ms))
-            allreduce_ms = float(ms.value) / reps
-        if allreduce_ms and world > 1:
-            busbw = 2.0 * (world - 1) / world * sync.nbytes / (allreduce_ms * 1e-3) / 1e9
-        barrier()
-    # cfg2/cfg3/cfg5: every rank runs a full sweep on its own shard (weak); cfg4: one global batch (strong)
-    if args.workload == "cfg4":
-        value = args.steps / elapsed
-        scaling = "strong"
-    else:
-        value = world * args.steps / elapsed
-        scaling = "weak"
+            barrier()
+            lib.event_record(e0)
+            for _ in range(reps):
+                comm.allreduce_sum_(buf)
+            lib.event_record(e1)
+            lib.sync()
+            if comm_kind == "rccl-direct":
+                lib.event_elapsed_ms(e0, e1, C.byref(ms))
+                allreduce_ms = float(ms.value) / reps
+            if allreduce_ms and world > 1:
+                busbw = 2.0 * (world - 1) / world * sync.nbytes / (allreduce_ms * 1e-3) / 1e9
+            barrier()
+        # cfg2/cfg3/cfg5: every rank runs a full sweep on its own shard (weak); cfg4: one global batch (strong)
+        if workload == "cfg4":
+            value, scaling = steps / elapsed, "strong"
+        else:
+            value, scaling = world * steps / elapsed, "weak"
+        roof, detail = rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc)
+        n = size or DEFAULT_SIZE[workload]
+        res = {
+            "value": value, "unit": "passes/s", "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup, "preroll_sweeps": preroll,
+            "scaling": scaling,
+            "config": {"workload": describe(workload, n, lazy), "parallelism": f"dp{world}", "lazy_fusion": bool(lazy),
+                       "graph_replay": bool(graph), "collective": comm_kind, "allreduce_bytes": sync.nbytes if use_dist else 0,
+                       "allreduce_overlapped_sweeps": sync.overlapped, "allreduce_panels": getattr(sync, "panels", 1),
+                       "allreduce_alone_ms": allreduce_ms, "allreduce_busbw_GBps": busbw},
+            "roofline": roof, "kernels": detail,
+        }
+        if workload == "cfg4":
+            res["tensors_per_s"] = (size or 8192) * value  # SURVEY 8e: batch rows through forward+backward per second
+        sync.close()
+        if comm is not None:
+            comm.close()
+        if captured is not None:
+            captured.close()
+        nd.set_lazy(prev_lazy)
+        return res
 
-    roofline = None
-    pmc = load_pmc_traffic()
-    if args.workload in ("cfg2", "cfg4", "cfg5"):
-        durs = kernel_ms.get("matmul", [])
-        n_gemm = {"cfg2": 3, "cfg4": 2, "cfg5": 5}[args.workload]
-        flop_per_launch = state["flops"] / n_gemm
-        if durs:
-            avg = sum(durs) / len(durs)
-            ach = flop_per_launch / (avg * 1e-3) / 1e12
-            traffic = pmc_mean(pmc, "k_gemm_f32_mfma") if args.workload == "cfg2" and not args.size else None
-            roofline = {"bound": "mfma", "kernel": "k_gemm_f32_mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                        "traffic_source": pmc.get("_source") if traffic else None,
-                        "launches": len(durs), "avg_launch_ms": avg, "flop_per_launch": flop_per_launch,
-                        "algorithmic_bytes_per_launch": 3 * 4 * (args.size or 4096) ** 2 if args.workload == "cfg2" else None}
-    elif args.lazy:
-        # fused: one reduce pass over (x, y) for the loss (8N), one two-output pass for both
-        # gradients (reads x, y once, writes x.grad and y.grad: 16N) = SURVEY 8d's fused lower bound
-        n = state["rows"]
-        fused_bytes = 24 * n
-        ach = fused_bytes / (ms_per_step * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_fused (reduce) + k_fused (two-output eval), run-time specialised",
-                    "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-                    "fused_algorithmic_bytes_per_sweep": fused_bytes, "eager_algorithmic_bytes_per_sweep": state["bytes"],
-                    "note": "achieved = fused bytes / whole-sweep time (3 launches incl. the reduction's finish); the eager figure (100N bytes) is not mixed in"}
-    else:
-        # dominant kernel of the eager chain: the f32 multiply (6 of the 11 launches per sweep:
-        # five read 2 x 4N and write 4N, the scaled stride-0 seed only writes 4N -> 64N bytes per sweep)
-        n = state["rows"]
-        durs = kernel_ms.get("multiply", [])
-        if durs:
-            avg = sum(durs) / len(durs)
-            bytes_per_launch = 64 * n / 6
-            ach = bytes_per_launch / (avg * 1e-3) / 1e9
-            tot_ms = sum(sum(v) for v in kernel_ms.values())
-            traffic = pmc_mean(pmc, "k_binary_fast<BMul, float, float, float, float") if not args.size else None
-            roofline = {"bound": "hbm", "kernel": "k_binary_fast<BMul,f32>", "achieved": ach, "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
-                        "traffic_source": pmc.get("_source") if traffic else None,
-                        "launches": len(durs), "avg_launch_ms": avg, "algorithmic_bytes_per_launch": bytes_per_launch,
-                        "whole_sweep": {"algorithmic_bytes": state["bytes"], "kernel_ms": tot_ms / args.steps,
-                                        "GB/s": state["bytes"] * args.steps / (tot_ms * 1e-3) / 1e9,
-                                        "per_kernel_ms": {k: sum(v) / len(v) for k, v in kernel_ms.items()}}}
+    head = run(args.workload, args.lazy, args.steps, args.warmup, graph=args.graph, size=args.size)
+    event_overhead_ms = timer.empty_bracket_ms()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, args.size)
 
-    if comm is not None:
-        comm.close()
-    if captured is not None:
-        captured.close()
+    # ---- the other BASELINE configs, same process, after the headline's timed region -------------------
+    secondary = None
+    if not args.no_secondary and not args.size and not args.graph:
+        secondary = {}
+        gc.collect()
+        lib.empty_cache()
+        k_sec, w_sec = min(args.steps, 10), min(args.warmup, 2)
+        if use_dist:
+            plan = [("cfg2_weak", "cfg2", False)] if args.workload == "cfg4" else [("cfg4_strong", "cfg4", False)]
+        else:
+            plan = [(f"{wl}{'_lazy' if lz else ''}", wl, lz) for wl in ("cfg3", "cfg4", "cfg5", "cfg2") for lz in (False, True)
+                    if not (wl in ("cfg5", "cfg2") and lz)]
+            plan = [p for p in plan if not (p[1] == args.workload and p[2] == bool(args.lazy))]
+        keep, keep_wl = None, None
+        for name, wl, lz in plan:
+            if wl != keep_wl:
+                keep, keep_wl = {}, wl
+                gc.collect()
+                lib.empty_cache()
+            try:
+                r = run(wl, lz, k_sec, w_sec, keep=keep)
+                r.pop("kernels" if wl in ("cfg2", "cfg5") else "_none", None)
+                secondary[name] = r
+            except Exception as e:  # a secondary config must never take the headline down
+                secondary[name] = {"error": f"{type(e).__name__}: {e}"}
+                if use_dist:
+                    raise
+        keep = None
+        gc.collect()
+
+    nd.DeviceArray._materialize = _plain_materialize
     if rank == 0:
-        n = args.size or {"cfg2": 4096, "cfg3": 100_000_000, "cfg4": 8192, "cfg5": 2048}[args.workload]
         line = {
             "metric": "forward+backward passes/sec on 4096x4096 fp32 matmul+elementwise graph",
-            "value": value, "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "preroll_sweeps": preroll,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "value": head["value"], "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "preroll_sweeps": head["preroll_sweeps"],
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {
-                "cfg2": f"cfg2: C=A@B ({n}x{n} fp32), C.backward(); 3 GEMMs NN/NT/TN; per-rank batch block, B.grad all-reduced",
-                "cfg3": f"cfg3: sum((sin(x)*y)**2).backward(), N={n} fp32" + (" [lazy fusion]" if args.lazy else " [eager: 11 kernels]"),
-                "cfg4": f"cfg4: sum(relu(X@W+b)).backward(), global batch {n} x 4096 -> 4096, row-sharded",
-                "cfg5": f"cfg5: second order on {n}x{n} matmul, 5 GEMMs"}[args.workload],
-                "parallelism": f"dp{world}", "graph_replay": bool(args.graph), "collective": comm_kind, "allreduce_bytes": sync.nbytes if use_dist else 0,
-                "allreduce_overlapped_sweeps": sync.overlapped,
-                "allreduce_alone_ms": allreduce_ms, "allreduce_busbw_GBps": busbw},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "config": head["config"],
+            "roofline": head["roofline"], "cpu_baseline": cpu,
         }
+        if "tensors_per_s" in head:
+            line["tensors_per_s"] = head["tensors_per_s"]
+        if args.workload != "cfg2" or args.lazy:
+            line["kernels"] = head["kernels"]
+        # per-kernel durations are HIP-event brackets around one backend call: they include the markers' own cost
+        # (this figure) and the launch gaps of multi-kernel calls; profiles/ holds the rocprofv3 kernel times
+        line["event_bracket_overhead_ms"] = event_overhead_ms
+        if secondary is not None:
+            line["secondary"] = secondary
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

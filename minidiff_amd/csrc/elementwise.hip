@@ -209,6 +209,7 @@ template <int U, class Body> __device__ __forceinline__ void md_ew_drive(const B
 }
 
 template <class F, class Tc, class To, class Tx, int MX, bool NT> struct UnaryBody {
+  static constexpr int kBlocksPerCU = 8;
   FastOp<Tx> x;
   Tc sx;
   To *out;
@@ -225,6 +226,9 @@ template <class F, class Tc, class To, class Tx, int MX, bool NT> struct UnaryBo
 };
 
 template <class F, class Tc, class To, class Ta, class Tb, int MA, int MB, bool NT> struct BinaryBody {
+  // three full streams (two operands + result): fewer resident waves ran faster — 400 MB multiply 203 us at 8 blocks
+  // per CU, 195 at 4, 190 at 2 (but one-operand kernels lose below 8: profiles/r2_ew_grid_ab.log)
+  static constexpr int kBlocksPerCU = (MA == OM_VEC && MB == OM_VEC) ? 4 : 8;
   FastOp<Ta> a;
   FastOp<Tb> b;
   Tc sa, sb;
@@ -247,6 +251,7 @@ template <class F, class Tc, class To, class Ta, class Tb, int MA, int MB, bool 
 };
 
 template <class T, class Tcnd, int MC, int MA, int MB> struct WhereBody {
+  static constexpr int kBlocksPerCU = 8;
   FastOp<Tcnd> c;
   FastOp<T> a, b;
   uint8_t sc;
@@ -392,7 +397,8 @@ template <class T> static int64_t fast_bytes(const FastOp<T> &f, const FastGeom 
 template <class Body, int U> static int launch_fast(const Body &body, const FastGeom &g, const char *what) {
   const int64_t nv = g.inner >> 2;
   const int64_t work = g.rows * nv + (g.rows == 1 ? 4 : 0);
-  const int grid = md_grid_for(work);
+  const int cap = md_max_blocks();  // (MDHIP_MAX_BLOCKS overrides the per-kernel choice: experiments)
+  const int grid = md_grid_for(work, MD_BLOCK, cap != MD_NUM_CUS * 8 ? cap : MD_NUM_CUS * Body::kBlocksPerCU);
   const int64_t stride = (int64_t)grid * MD_BLOCK;
   FastGrid fg;
   fg.rows = g.rows;

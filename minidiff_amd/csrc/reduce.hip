@@ -240,6 +240,7 @@ template <class R, class Tacc, class Tdst, int Q, bool FINAL, bool NT>
 __global__ void __launch_bounds__(MD_BLOCK) k_reduce_cols_sweep(const Tacc *__restrict__ x, int64_t n_out, int64_t n_red, int64_t rs,
                                                                int64_t chunk, Tdst *__restrict__ dst) {
   constexpr int V = 16 / sizeof(Tacc);
+  constexpr int RB = 3;  // rows per batch: RB * Q 16-B loads per lane
   const int64_t s = blockIdx.x, r0 = s * chunk;
   int64_t r1 = r0 + chunk;
   if (r1 > n_red) r1 = n_red;
@@ -250,26 +251,50 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_cols_sweep(const Tacc *__re
     for (int j = 0; j < V; ++j) acc[q][j] = R::template identity<Tacc>();
   const MdVec<Tacc, V> *p = reinterpret_cast<const MdVec<Tacc, V> *>(x) + threadIdx.x;
   const int64_t rsv = rs / V;
-  int64_t r = r0;
-  for (; r + 3 <= r1; r += 3) {
-    MdVec<Tacc, V> t[3][Q];
+  // Two batches in flight (software pipeline): with one wave per SIMD nothing else covers the gap between "all
+  // loads of this batch have landed" and "the next batch is issued" (one batch per trip ran at 5.0 TB/s). The
+  // batch index of a prefetch past the end is clamped: a redundant, discarded load instead of a branch.
+  const int64_t nb = (r1 - r0) / RB;
+  MdVec<Tacc, V> t[2][RB][Q];
+  auto load = [&](int buf, int64_t b) {
+    const int64_t r = r0 + (b < nb ? b : nb - 1) * RB;
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
+    for (int u = 0; u < RB; ++u)
 #pragma unroll
-      for (int q = 0; q < Q; ++q) t[u][q] = md_ld_once<NT>(p + (r + u) * rsv + q * MD_BLOCK);
+      for (int q = 0; q < Q; ++q) t[buf][u][q] = md_ld_once<NT>(p + (r + u) * rsv + q * MD_BLOCK);
+  };
+  auto add = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
+    for (int u = 0; u < RB; ++u)
 #pragma unroll
       for (int q = 0; q < Q; ++q)
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[q][j] = R::combine(acc[q][j], t[u][q].v[j]);
+        for (int j = 0; j < V; ++j) acc[q][j] = R::combine(acc[q][j], t[buf][u][q].v[j]);
+  };
+  if (nb > 0) {
+    load(0, 0);
+    int64_t b = 0;
+    for (; b + 1 < nb; b += 2) {
+      // (one basic block, and scheduling barriers to pin "issue the next batch, THEN consume the landed one": with
+      // a conditional consumer the compiler sinks the prefetch into the branch, and left alone it sinks loads
+      // behind the adds — either way the queue drains every trip)
+      load(1, b + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      add(0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(0, b + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      add(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (b < nb) add(0);  // odd batch count: the last batch sits in buffer 0
   }
-  for (; r < r1; ++r) {
+  for (int64_t r = r0 + nb * RB; r < r1; ++r) {
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      const MdVec<Tacc, V> t = p[r * rsv + q * MD_BLOCK];
+      const MdVec<Tacc, V> tt = p[r * rsv + q * MD_BLOCK];
 #pragma unroll
-      for (int j = 0; j < V; ++j) acc[q][j] = R::combine(acc[q][j], t.v[j]);
+      for (int j = 0; j < V; ++j) acc[q][j] = R::combine(acc[q][j], tt.v[j]);
     }
   }
   Tdst *d = FINAL ? dst : dst + s * n_out;
