@@ -316,6 +316,9 @@ int mdhip_vm_jit_stats(int64_t stats[2]);
 /* One communicator per process (one process per GPU). uid is the 128-byte
  * ncclUniqueId produced on rank 0 and distributed by the launcher. */
 #define MDHIP_UID_BYTES 128
+/* Can this process reach RCCL at all (opens librccl; creates nothing)? Ranks agree on the answer BEFORE
+ * ncclCommInitRank, which would wait for the missing ones for ever (minidiff_amd/dp.py RcclComm). */
+int mdhip_comm_probe(void);
 int mdhip_comm_get_unique_id(uint8_t uid[MDHIP_UID_BYTES]);
 int mdhip_comm_init(int nranks, int rank, const uint8_t uid[MDHIP_UID_BYTES]);
 int mdhip_comm_allreduce_sum(void *buf, size_t count, int dtype); /* in place, on the stream */

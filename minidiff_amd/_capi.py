@@ -126,6 +126,7 @@ _PROTOTYPES = {
     "mdhip_vm_eval_multi": [_P(VmProgram), _P(ArrayDesc), C.c_int],
     "mdhip_vm_eval_reduce_cols": [_P(VmProgram), C.c_int, _P(ArrayDesc), _P(ArrayDesc)],
     "mdhip_vm_jit_probe_multi": [_P(VmProgram), C.c_int, C.c_char_p, C.c_size_t],
+    "mdhip_comm_probe": [],
     "mdhip_comm_get_unique_id": [_P(C.c_uint8)],
     "mdhip_comm_init": [C.c_int, C.c_int, _P(C.c_uint8)],
     "mdhip_comm_allreduce_sum": [C.c_void_p, C.c_size_t, C.c_int],

@@ -146,6 +146,8 @@ int mdhip_alloc(size_t nbytes, void **ptr_out) {
   return MDHIP_OK;
 }
 
+static void comm_guard_free(const void *p, size_t bytes);  // (RCCL section below)
+
 int mdhip_free(void *p) {
   if (!p) return MDHIP_OK;
   State &s = S();
@@ -153,6 +155,7 @@ int mdhip_free(void *p) {
   auto it = s.live.find(p);
   if (it == s.live.end()) return md_fail(MDHIP_EVALUE, "free of unknown device pointer %p", p);
   size_t r = it->second;
+  comm_guard_free(p, r);
   s.live.erase(it);
   s.in_use -= (int64_t)r;
   auto ow = s.owner.find(p);
@@ -387,7 +390,23 @@ static struct {
   hipStream_t cstream = nullptr;
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   bool pending = false;
+  // buffers of the collectives issued on cstream and not yet joined by mdhip_comm_wait
+  std::vector<std::pair<const char *, size_t>> in_flight;
 } R;
+
+// The caching allocator hands a freed block to the next request at once because everything runs on ONE stream;
+// a collective in flight on the second stream breaks that assumption for ITS buffer only: a block that overlaps
+// one (a gradient dropped before GradSync() joined the streams) is released behind the collective.
+static void comm_guard_free(const void *p, size_t bytes) {
+  if (!R.pending) return;
+  const char *lo = (const char *)p, *hi = lo + bytes;
+  for (auto &rg : R.in_flight) {
+    if (lo < rg.first + rg.second && rg.first < hi) {
+      (void)hipStreamWaitEvent(md_stream(), R.ev_done, 0);
+      return;
+    }
+  }
+}
 
 static int rccl_load() {
   if (R.h) return MDHIP_OK;
@@ -444,6 +463,7 @@ int mdhip_comm_allreduce_sum(void *buf, size_t count, int dtype) {
   if (!R.comm) return md_fail(MDHIP_ERUNTIME, "communicator not initialised");
   int nt;
   MD_TRY(rccl_dtype(dtype, &nt));
+  MD_TRY(mdhip_comm_wait());  // RCCL wants one issue order per communicator: stay behind collectives still in flight
   return rccl_check(R.AllReduce(buf, buf, count, nt, MD_NCCL_SUM, R.comm, md_stream()), "ncclAllReduce");
 }
 int mdhip_comm_allreduce_sum_async(void *buf, size_t count, int dtype) {
@@ -468,13 +488,18 @@ int mdhip_comm_allreduce_sum_async(void *buf, size_t count, int dtype) {
   MD_TRY(rccl_check(R.AllReduce(buf, buf, count, nt, MD_NCCL_SUM, R.comm, R.cstream), "ncclAllReduce"));
   MD_TRY(md_hip_check(hipEventRecord(R.ev_done, R.cstream), "hipEventRecord"));
   R.pending = true;
+  R.in_flight.emplace_back((const char *)buf, count * md_dtype_size(dtype));
   return MDHIP_OK;
 }
 int mdhip_comm_wait(void) {
   if (!R.pending) return MDHIP_OK;
   R.pending = false;
+  R.in_flight.clear();
+  // (several collectives may have been issued since the last join: they run in order on cstream, so the
+  // event recorded behind the LAST one covers them all)
   return md_hip_check(hipStreamWaitEvent(md_stream(), R.ev_done, 0), "hipStreamWaitEvent");
 }
+int mdhip_comm_probe(void) { return rccl_load(); }
 int mdhip_comm_destroy(void) {
   if (!R.comm) return MDHIP_OK;
   if (R.cstream) {
@@ -485,6 +510,7 @@ int mdhip_comm_destroy(void) {
     R.cstream = nullptr;
     R.ev_ready = R.ev_done = nullptr;
     R.pending = false;
+    R.in_flight.clear();
   }
   (void)hipStreamSynchronize(md_stream());
   int st = R.CommDestroy(R.comm);

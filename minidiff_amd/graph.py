@@ -33,6 +33,12 @@ class CapturedSweep:
                 self._lib.graph_end(C.byref(handle))
             except RuntimeError:
                 pass
+            if handle.value:  # the capture itself closed cleanly: give its graph and reserved blocks back
+                try:
+                    self._lib.graph_destroy(handle)
+                except RuntimeError:
+                    pass
+            self._graph = None
             raise
         self._lib.graph_end(C.byref(handle))
         self._graph = handle

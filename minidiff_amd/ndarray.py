@@ -1551,7 +1551,9 @@ def _as3d(x: DeviceArray, batch_shape: tuple):
     return full._view(full._offset, (B, r, c), (st[0], full._strides[-2], full._strides[-1]))
 
 
-def matmul(a, b, **_):
+def matmul(a, b, out=None, **_):
+    """np.matmul (numpy.py:84). `out`: like NumPy's — a C-contiguous array of the result's shape and dtype that
+    receives the product (dp.GradSync points it at a row panel of the all-reduce bucket)."""
     a, b = asarray(a), asarray(b)
     if a.ndim == 0 or b.ndim == 0:
         raise ValueError("matmul: Input operand does not have enough dimensions (has 0, gufunc core with signature (n?,k),(k,m?)->(n?,m?) requires 1)")
@@ -1573,7 +1575,14 @@ def matmul(a, b, **_):
             f"matmul: Input operand 1 has a mismatch in its core dimension 0, with gufunc signature (n?,k),(k,m?)->(n?,m?) (size {b.shape[-2]} is different from {a.shape[-1]})")
     batch = _broadcast_shapes(a.shape[:-2], b.shape[:-2])
     M, N = a.shape[-2], b.shape[-1]
-    res = DeviceArray.empty(batch + (M, N), odt)
+    if out is not None:
+        if not isinstance(out, DeviceArray) or a_vec or b_vec or out.shape != batch + (M, N) or out.dtype != odt or not out.is_c_contiguous:
+            raise ValueError("matmul: out must be a C-contiguous DeviceArray with the shape and dtype of the result")
+        _before_write(out)
+        out = _unalias_out(out, a, b)
+        res = out
+    else:
+        res = DeviceArray.empty(batch + (M, N), odt)
     B = _prod(batch)
     a3 = _as3d(a, batch)
     b3 = _as3d(b, batch)
@@ -1591,6 +1600,14 @@ def matmul(a, b, **_):
         shp = batch + (M,)
         return res._view(res._offset, shp, _c_strides(shp))
     return res
+
+
+def _unalias_out(out, *operands):
+    """matmul reads its operands while it writes: an `out` that shares a block with one of them is refused."""
+    for x in operands:
+        if x._buf is not None and x._buf is out._buf:
+            raise ValueError("matmul: out must not overlap an operand")
+    return out
 
 
 def dot(a, b, **_):

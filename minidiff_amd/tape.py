@@ -128,7 +128,15 @@ def build_engine(B, name: str = "engine"):
                 if vjp is None or not isinstance(inp, Tensor) or not inp.allow_grad:
                     continue
                 kw = self.kwargs if self.pass_kwargs else {}
-                g = vjp(*self.inputs, grad, **kw)
+                g = None
+                if pending and pending.get(id(inp)) == 1 and inp.grad is None and not E.grad_allowed_():
+                    # the ONLY contribution to a hooked leaf, first order: its hook may produce the gradient itself
+                    # (dp.GradSync: the weight gradient of a matmul in row panels, straight into the all-reduce bucket)
+                    producer = E.grad_ready_hooks[id(inp)][2]
+                    if producer is not None:
+                        g = producer(self, i, grad)
+                if g is None:
+                    g = vjp(*self.inputs, grad, **kw)
                 if g.shape != inp.shape:
                     g = E.unbroadcast(g, inp.shape)
                 inp.grad = g if inp.grad is None else inp.grad + g
@@ -194,8 +202,11 @@ def build_engine(B, name: str = "engine"):
     # id(tensor) -> (tensor, fn); fn(tensor) runs inside backward() as soon as tensor.grad is final
     E.grad_ready_hooks = {}
 
-    def register_grad_ready_hook(tensor, fn):
-        E.grad_ready_hooks[id(tensor)] = (tensor, fn)
+    def register_grad_ready_hook(tensor, fn, producer=None):
+        """`fn(tensor)` runs the moment `tensor.grad` is final inside backward(). `producer(node, input_index, grad)`
+        (optional) is offered the computation of that gradient when it has a single contribution: it returns the
+        gradient Tensor, or None to leave it to the op's own vjp."""
+        E.grad_ready_hooks[id(tensor)] = (tensor, fn, producer)
 
     def remove_grad_ready_hook(tensor):
         E.grad_ready_hooks.pop(id(tensor), None)

@@ -63,12 +63,14 @@ def make_cfg3(md, n=100_000_000, seed=3):
 def make_cfg4(md, batch=8192, d_in=4096, d_out=4096, seed=4, rank=0, world=1):
     """sum(relu(X @ W + b)).backward(), relu := where(z > 0, z, 0); rank r owns
     rows [r*batch/world, (r+1)*batch/world) of X; W, b replicated."""
-    rows = batch // world
+    from .dp import shard_rows
+    shard = shard_rows(batch, rank, world)  # ValueError if the batch does not split evenly: no silently dropped rows
+    rows = shard.stop - shard.start
     rng = np.random.default_rng(seed)
     Xfull = rng.standard_normal((batch, d_in), dtype=np.float32)
     Wh = rng.standard_normal((d_in, d_out), dtype=np.float32) / np.float32(64.0)
     bh = rng.standard_normal((d_out,), dtype=np.float32)
-    X = md.Tensor(np.ascontiguousarray(Xfull[rank * rows:(rank + 1) * rows]))
+    X = md.Tensor(np.ascontiguousarray(Xfull[shard]))
     del Xfull
     W = md.Tensor(Wh, allow_grad=True)
     b = md.Tensor(bh, allow_grad=True)

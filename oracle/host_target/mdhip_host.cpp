@@ -396,6 +396,7 @@ int mdhip_vm_eval_reduce_cols(const mdhip_vm_program *pr, int op, const mdhip_ar
 }
 
 // data-parallel entry points: the double has no collective; world size 1 only.
+int mdhip_comm_probe(void) { return MDHIP_OK; }
 int mdhip_comm_get_unique_id(uint8_t uid[MDHIP_UID_BYTES]) { memset(uid, 0, MDHIP_UID_BYTES); return MDHIP_OK; }
 static int g_nranks = 0;
 int mdhip_comm_init(int nranks, int, const uint8_t *) {

@@ -46,6 +46,47 @@ def main():
     sync()
     assert np.abs(st["W"].grad.as_numpy() - full_state["W"].grad.as_numpy()).max() / np.abs(full_state["W"].grad.as_numpy()).max() < 1e-5
 
+    # the weight gradient in ROW PANELS: W.grad = X^T @ G is produced 256 rows at a time inside the bucket and every panel
+    # is all-reduced on its own (dp.GradSync._produce); the result must equal the full-batch gradient like before
+    big_full, big_full_step = workloads.make_cfg4(md, batch=64, d_in=1024, d_out=48, rank=0, world=1)
+    big_full_step()
+    bst, bstep = workloads.make_cfg4(md, batch=64, d_in=1024, d_out=48, rank=rank, world=world)
+    calls = []
+    real = comm.allreduce_sum_
+    comm.allreduce_sum_ = lambda arr: (calls.append(arr.size), real(arr))[1]
+    bsync = dp.GradSync(md, bst["params"], comm, panels=4)
+    assert bsync.panels == 4
+    for sweep in range(2):
+        del calls[:]
+        bstep()
+        bsync()
+        assert calls == [256 * 48] * 4 + [48], calls          # four W panels from inside the GEMM loop, then the bias slot
+        assert bsync.panel_collectives == 4 * (sweep + 1) and bsync.overlapped == sweep + 1
+        for name in ("W", "b"):
+            got, exp = bst[name].grad.as_numpy(), big_full[name].grad.as_numpy()
+            assert got.shape == exp.shape
+            err = np.abs(got - exp).max() / np.abs(exp).max()
+            assert err < 1e-5, (name, err)
+        # the gradients ARE views of the bucket (no copy of W.grad into it)
+        assert np.shares_memory(bst["W"].grad._data, bsync.bucket) and np.shares_memory(bst["b"].grad._data, bsync.bucket)
+    bsync.close()
+    # un-chunked reference of the same sweep: bit-equal on this rank's shard sums? (different GEMM blocking may round
+    # differently on a device; on NumPy the panel products are the same dot products) -> equal after the same all-reduce
+    usync = dp.GradSync(md, bst["params"], comm, panels=1)
+    del calls[:]
+    bstep()
+    usync()
+    assert calls == [1024 * 48 + 48], calls
+    assert np.abs(bst["W"].grad.as_numpy() - big_full["W"].grad.as_numpy()).max() / np.abs(big_full["W"].grad.as_numpy()).max() < 1e-5
+    usync.close()
+    comm.allreduce_sum_ = real
+    # a batch that does not split evenly is refused, not truncated
+    try:
+        workloads.make_cfg4(md, batch=63, d_in=24, d_out=40, rank=rank, world=world)
+        raise AssertionError("uneven batch accepted")
+    except ValueError:
+        pass
+
     # cfg2: every rank has its own batch block A_r; B.grad = sum_r A_r^T @ G_r, one un-bucketed all-reduce
     st2, step2 = workloads.make_cfg2(md, n=48, rank=rank)
     sync2 = dp.GradSync(md, st2["params"][:1], comm, overlap=False)
@@ -103,6 +144,32 @@ def main():
         rc.close()
     finally:
         _capi.load = real_load
+    # a failure on ONE rank (rank 0 cannot produce the id; or one rank cannot load librccl) must surface on EVERY rank,
+    # before anybody enters ncclCommInitRank, so that all of them can fall back together
+    class _FailingId(_Recorder):
+        def comm_get_unique_id(self, uid):
+            raise RuntimeError("librccl missing (injected)")
+
+    class _FailingProbe(_Recorder):
+        def comm_probe(self):
+            if rank == 1:
+                raise RuntimeError("no RCCL here (injected)")
+
+    for stand_in in (_FailingId, _FailingProbe):
+        bad = stand_in()
+        _capi.load = lambda bad=bad: bad
+        try:
+            try:
+                dp.RcclComm(rank, world, dist)
+                raise AssertionError("rendezvous should have failed on every rank")
+            except RuntimeError as e:
+                assert "injected" in str(e), e
+        finally:
+            _capi.load = real_load
+        assert not [c for c in bad.calls if isinstance(c, tuple)], bad.calls   # nobody reached comm_init
+    flags = [None] * world
+    dist.all_gather_object(flags, True)   # the control plane is still in step after the failures
+    assert all(flags)
     expected_uid = bytes((37 * i + 11) % 251 for i in range(_capi.UID_BYTES))
     inits = [c for c in rec.calls if isinstance(c, tuple)]
     assert inits == [("init", world, rank, expected_uid)], inits

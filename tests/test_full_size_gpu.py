@@ -150,3 +150,51 @@ def test_matmul_with_more_than_2_to_31_outputs_gpu(lib, on_gpu):
     got = np.asarray(c[:, nd.asarray(cols)])
     ref = a.astype(np.float64) @ b[:, cols].astype(np.float64)
     assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_cfg4_rank_shard_shapes(engines, on_gpu, world):
+    """The per-rank GEMM shapes of the batch-sharded cfg4 sweep (at 8 ranks (1024 x 4096 x 4096) NN and
+    (4096 x 1024 x 4096) TN): one rank's shard on the device against the oracle's closed form for the device's own
+    mask, and the shard gradients of all ranks summed on the host against the full-batch gradient."""
+    assert on_gpu
+    dev, _ = engines
+    from minidiff_amd import workloads
+    rank = world - 1   # the last shard (its rows end the batch)
+    s_d, step_d = workloads.make_cfg4(dev, rank=rank, world=world)
+    step_d()
+    X, W, b = s_d["X"].as_numpy(), s_d["W"].as_numpy(), s_d["b"].as_numpy()
+    assert X.shape == (8192 // world, 4096)
+    with dev.no_grad():
+        z = (s_d["X"] @ s_d["W"] + s_d["b"]).as_numpy()
+    assert _rel(z, X @ W + b) < 1e-5
+    m = z > 0
+    assert _rel(s_d["W"].grad.as_numpy(), X.astype(np.float64).T @ m.astype(np.float64)) < 1e-5
+    assert _rel(s_d["b"].grad.as_numpy(), m.sum(axis=0, dtype=np.float64)) < 1e-6
+
+
+def test_weight_gradient_in_row_panels_is_bit_identical(engines, on_gpu):
+    """dp.GradSync produces W.grad = X^T @ G in row panels inside the all-reduce bucket (one GEMM per panel, each
+    followed by its collective on the second stream). Every output element is the same k-ordered fma chain, so at
+    world size 1 the panelled, all-reduced gradient must equal the plain sweep's bit for bit — at the rank-shard
+    shape of 8 ranks and at the full batch."""
+    assert on_gpu
+    from minidiff_amd import dp, workloads
+    hip, _ = engines
+    comm = dp.RcclComm(0, 1)
+    try:
+        for kw in ({"batch": 1024}, {"batch": 8192}):
+            st, step = workloads.make_cfg4(hip, **kw)
+            step()
+            ref = {k: st[k].grad.as_numpy().copy() for k in ("W", "b")}
+            for panels in (4, 8, 1):
+                sync = dp.GradSync(hip, st["params"], comm, force=True, panels=panels)
+                for _ in range(2):
+                    step()
+                    sync()
+                assert sync.overlapped == 2 and sync.panel_collectives == (2 * panels if panels > 1 else 0)
+                for k in ("W", "b"):
+                    np.testing.assert_array_equal(st[k].grad.as_numpy(), ref[k])
+                sync.close()
+    finally:
+        comm.close()
