@@ -125,7 +125,7 @@ def load_pmc_traffic():
 
 
 def pmc_mean(pmc, prefix):
-    vals = [v["hbm_bytes_per_launch"] for k, v in pmc.get("kernels", {}).items() if k.startswith(prefix)]
+    vals = [v["hbm_bytes_per_launch"] for k, v in pmc.get("kernels", {}).items() if k.startswith(prefix) and not k.endswith("]")]
     return sum(vals) / len(vals) if vals else None
 
 
@@ -274,7 +274,7 @@ def rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc):
         avg = _mean(durs)
         tot_ms = sum(sum(v) for v in kernel_ms.values())
         steps = len(kernel_ms.get("sin", [])) or 1
-        committed = pmc_mean(pmc, "k_binary_fast<BMul, float, float, float, float") if not size else None
+        committed = pmc_mean(pmc, "k_ew_fast<BinaryBody<BMul, float, float, float, float, 1, 1, true>") if not size else None
         main = _hbm("k_ew_fast<BinaryBody<BMul,f32,f32>> (multiply, both operands streamed)", 12 * n, avg, launches=len(durs),
                     traffic_committed=committed, traffic_committed_source=pmc.get("_source") if committed else None,
                     whole_sweep={"algorithmic_bytes": state["bytes"], "kernel_ms": tot_ms / steps,
