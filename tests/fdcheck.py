@@ -1,4 +1,4 @@
-"""Finite-difference gradient checker — this repo's counterpart of the
+"""TEST INFRASTRUCTURE. Finite-difference gradient checker — this repo's counterpart of the
 reference's test harness (reference: minidiff/utils.py:104-159
 `calculate_finite_differences`, :163-197 `compute_grads`), written against the
 tape API so it runs on any engine (HIP table on the GPU box, NumPy oracle).
