@@ -59,3 +59,96 @@ class CapturedSweep:
             self.close()
         except Exception:
             pass
+
+
+class SweepCache:
+    """Replays a repeated sweep automatically: the device-side half of the reference's `reuse_graph`
+    (minidiff/caching.py:14-65 memoises the TRAVERSAL of a graph it has seen; here the whole sweep's kernel
+    sequence is memoised as a hipGraph), keyed by the tape's structural hash.
+
+        cache = SweepCache(md)
+        for batch in stream:
+            x._data[...] = batch                  # new values go INTO the resident inputs
+            out = cache.run(step)                 # 1st call: eager; 2nd: captured; then one hipGraphLaunch each
+
+    `step()` records forward + backward on the tape (inside `md.reuse_graph()`, entered here), so every eager or
+    capturing run yields the structural hash of its root (`md.last_root_hash`). A captured graph is kept under
+    (step, hash); it is only replayed while the sweep keeps that structure:
+      * a run whose hash differs from the previous one of the same `step` (another branch taken, another op) is
+        simply a different entry: it runs eagerly, then captures its own graph;
+      * a replay executes no Python, so it cannot see a change by itself: every `validate_every`-th call of a
+        captured entry runs eagerly instead and compares hashes; on a mismatch the stale graph is destroyed.
+    A sweep that cannot be captured (a synchronising call inside it; the CPU test double) stays eager."""
+
+    def __init__(self, md, validate_every: int = 0):
+        self.md = md
+        self.validate_every = int(validate_every)
+        self._entries = {}      # (id(step), hash) -> dict(seen, sweep, failed)
+        self._current = {}      # id(step) -> hash of its latest eager/capturing run
+        self._calls = {}        # id(step) -> calls since the last eager run
+        self.stats = {"eager": 0, "captured": 0, "replayed": 0, "invalidated": 0, "uncapturable": 0}
+
+    def _eager(self, step):
+        with self.md.reuse_graph():
+            out = step()
+            return out, self.md.last_root_hash
+
+    def run(self, step):
+        sid = id(step)
+        h = self._current.get(sid)
+        entry = self._entries.get((sid, h)) if h is not None else None
+        if entry is not None and entry["sweep"] is not None:
+            n = self._calls[sid] = self._calls.get(sid, 0) + 1
+            if not (self.validate_every and n % self.validate_every == 0):
+                self.stats["replayed"] += 1
+                return entry["sweep"].replay()
+            out, h2 = self._eager(step)     # validation run: same structure?
+            self.stats["eager"] += 1
+            if h2 != h:
+                entry["sweep"].close()
+                del self._entries[(sid, h)]
+                self.stats["invalidated"] += 1
+                self._current[sid] = h2
+                self._entries.setdefault((sid, h2), {"seen": 1, "sweep": None, "failed": False})
+            return out
+        if entry is not None and entry["seen"] >= 1 and not entry["failed"]:
+            # second sighting of this structure: capture it (the capture run executes the sweep once more)
+            try:
+                with self.md.reuse_graph():
+                    sweep = CapturedSweep(step, warmup=0)
+                    h2 = self.md.last_root_hash
+            except RuntimeError:
+                entry["failed"] = True
+                self.stats["uncapturable"] += 1
+                out, h2 = self._eager(step)
+                self.stats["eager"] += 1
+                self._current[sid] = h2
+                return out
+            if h2 != h:   # the structure moved between two consecutive runs: do not trust this capture
+                sweep.close()
+                self._current[sid] = h2
+                self._entries.setdefault((sid, h2), {"seen": 1, "sweep": None, "failed": False})
+                self.stats["eager"] += 1
+                return sweep.outputs
+            entry["sweep"] = sweep
+            self._calls[sid] = 0
+            self.stats["captured"] += 1
+            return sweep.outputs
+        out, h2 = self._eager(step)
+        self.stats["eager"] += 1
+        self._current[sid] = h2
+        e = self._entries.setdefault((sid, h2), {"seen": 0, "sweep": None, "failed": False})
+        e["seen"] += 1
+        return out
+
+    def close(self):
+        for e in self._entries.values():
+            if e["sweep"] is not None:
+                e["sweep"].close()
+        self._entries.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -38,6 +38,19 @@ def _visit(node, seen, out):
         out.append(t)
 
 
+def _visit_paths(node, prefix, seen, out):
+    """Like _visit, but records for every tensor the input-index walk that reaches it from the root node."""
+    if node is None:
+        return
+    for i, t in enumerate(node.inputs):
+        if not hasattr(t, "op_node") or id(t) in seen:
+            continue
+        seen.add(id(t))
+        path = prefix + (i,)
+        _visit_paths(t.op_node, path, seen, out)
+        out.append(path)
+
+
 def build_engine(B, name: str = "engine"):
     """Create the md-like namespace (Tensor, ops, helpers) over backend table `B`."""
     E = types.SimpleNamespace()
@@ -77,6 +90,45 @@ def build_engine(B, name: str = "engine"):
             grad_on.set(self.saved[0])
             new_grads_on.set(self.saved[1])
 
+    # ----------------------------------------------- reuse_graph (tape memoisation) ----
+    # Counterpart of the reference's minidiff/caching.py:14-65: inside `with md.reuse_graph():` every op node
+    # carries a STRUCTURAL id (the ids of its tensor inputs' producers, -1 for leaves and non-tensors, and the
+    # op's name: topology.py:46-74), the root's hash keys a cache of the backward traversal — stored as
+    # input-index walks from the root, so a later graph of the same structure reuses it without another
+    # topological sort (topology.py:152-162). `E.last_root_hash` exposes the hash of the latest backward()
+    # root: minidiff_amd.graph.SweepCache keys captured hipGraphs by it.
+    caching_on = ContextVar(f"{name}_caching_graph", default=False)
+    cached_paths = ContextVar(f"{name}_cached_indices", default=None)
+    E.last_root_hash = None
+
+    class reuse_graph:
+        def __enter__(self):
+            self.prev = (caching_on.get(), cached_paths.get())
+            caching_on.set(True)
+            cached_paths.set({})
+            return self
+
+        def __exit__(self, *exc):
+            caching_on.set(self.prev[0])
+            cached_paths.set(self.prev[1])
+
+    E.reuse_graph = reuse_graph
+    E.currently_caching = caching_on.get
+
+    def backward_paths_for_root(root):
+        if not caching_on.get():
+            raise ValueError("Not currently preserving graph")
+        table = cached_paths.get()
+        h = root.hash
+        paths = table.get(h)
+        if paths is None:
+            paths = []
+            _visit_paths(root, (), set(), paths)
+            paths = table[h] = tuple(paths)
+        return paths
+
+    E.backward_paths_for_root = backward_paths_for_root
+
     E.no_grad, E.enable_grad, E.disable_new_grads = no_grad, enable_grad, disable_new_grads
     E.grad_allowed_ = grad_on.get
     E.set_allow_grad = grad_on.set
@@ -101,7 +153,7 @@ def build_engine(B, name: str = "engine"):
     class Node:
         """One recorded op: inputs + one vjp closure per input."""
 
-        __slots__ = ("vjps", "inputs", "kwargs", "name", "pass_kwargs", "tensor_inputs")
+        __slots__ = ("vjps", "inputs", "kwargs", "name", "pass_kwargs", "tensor_inputs", "op_ids")
 
         def __init__(self, vjps, inputs, kwargs, name, pass_kwargs):
             self.vjps = vjps
@@ -112,6 +164,20 @@ def build_engine(B, name: str = "engine"):
             self.tensor_inputs = [x for x in inputs if isinstance(x, Tensor)]
             for t in self.tensor_inputs:
                 t.graph_refs += 1
+            self.op_ids = None
+            if caching_on.get():  # structural id (topology.py:52-63)
+                ids = []
+                for x in inputs:
+                    if not isinstance(x, Tensor) or x.is_leaf or x.op_node is None or x.op_node.op_ids is None:
+                        ids.append(-1)
+                    else:
+                        ids.append(x.op_node.op_ids)
+                ids.append(self.name)
+                self.op_ids = tuple(ids)
+
+        @property
+        def hash(self):
+            return hash(self.op_ids)
 
         def push(self, grad, pending=None):
             """Chain rule for this node: evaluate each vjp, undo broadcasting, accumulate.
@@ -153,7 +219,17 @@ def build_engine(B, name: str = "engine"):
                 retain_grads = True
                 if cleanup_mode == "destroy":
                     cleanup_mode = "prune"
-            path = _toposort(self)
+            if caching_on.get() and self.op_ids is not None:
+                path = []
+                for walk in backward_paths_for_root(self):   # memoised order, re-bound to THIS graph's tensors
+                    node = self
+                    for i in walk:
+                        t = node.inputs[i]
+                        node = t.op_node
+                    path.append(t)
+                E.last_root_hash = self.hash
+            else:
+                path = _toposort(self)
             if reset_grads:
                 for t in path:
                     t.grad = None

@@ -92,3 +92,94 @@ def test_synchronising_call_aborts_capture(engines):
     out = step()  # capture was aborted; eager work goes on
     gx, _ = _cfg3_expected(state["x"].as_numpy(), state["y"].as_numpy())
     np.testing.assert_allclose(out["x"].grad.as_numpy(), gx, rtol=2e-5, atol=1e-6)
+
+
+# ---- reuse_graph: tape-side memoisation (reference minidiff/caching.py) and the hipGraph cache keyed by it ----
+def test_reuse_graph_memoises_traversal_by_structure(engines):
+    """Inside `md.reuse_graph()` two graphs of one structure share ONE cached traversal (keyed by the root's
+    structural hash), a different structure gets its own, and gradients equal the un-cached ones."""
+    for md in engines:
+        def sweep(kind):
+            x = md.Tensor(np.arange(6.0).reshape(2, 3) / 4, allow_grad=True)
+            y = md.Tensor(np.full((2, 3), 2.0), allow_grad=True)
+            f = md.sum((md.sin(x) * y) ** 2 + x * y) if kind == 0 else md.sum(md.cos(x) * y)
+            f.backward()
+            return np.asarray(x.grad.as_numpy()).copy(), np.asarray(y.grad.as_numpy()).copy(), f
+
+        plain = sweep(0)
+        assert plain[2].op_node.op_ids is None          # no structural ids outside the context
+        with md.reuse_graph():
+            a = sweep(0)
+            h_a = md.last_root_hash
+            b = sweep(0)
+            assert md.last_root_hash == h_a
+            c = sweep(1)
+            h_c = md.last_root_hash
+            assert h_c != h_a
+            assert len(md.backward_paths_for_root(a[2].op_node)) == len(md.backward_paths_for_root(b[2].op_node))
+            assert md.backward_paths_for_root(a[2].op_node) is md.backward_paths_for_root(b[2].op_node)   # memoised
+        for got in (a, b):
+            np.testing.assert_array_equal(got[0], plain[0])
+            np.testing.assert_array_equal(got[1], plain[1])
+        with pytest.raises(ValueError):
+            md.backward_paths_for_root(a[2].op_node)     # "Not currently preserving graph" (caching.py:33-34)
+
+
+def test_sweep_cache_falls_back_to_eager_on_cpu_double(engines, on_gpu):
+    if on_gpu:
+        pytest.skip("CPU double behaviour")
+    from minidiff_amd.graph import SweepCache
+    hip, _ = engines
+    state, step = workloads.make_cfg3(hip, n=1000)
+    ref = step()["x"].grad.as_numpy().copy()
+    with SweepCache(hip) as cache:
+        for _ in range(4):
+            out = cache.run(step)
+            np.testing.assert_array_equal(out["x"].grad.as_numpy(), ref)
+        assert cache.stats["uncapturable"] == 1 and cache.stats["replayed"] == 0 and cache.stats["eager"] == 4
+
+
+@pytest.mark.gpu
+def test_sweep_cache_replays_and_recaptures_changed_graph(engines):
+    """1st run eager, 2nd captured, then replays; when the sweep's structure changes (a flag read by `step`),
+    the validation run notices the new structural hash, drops the stale graph, and the new structure is captured."""
+    from minidiff_amd.graph import SweepCache
+    hip, _ = engines
+    n = 1 << 16
+    rng = np.random.default_rng(3)
+    xh, yh = rng.standard_normal(n, dtype=np.float32), rng.standard_normal(n, dtype=np.float32)
+    x, y = hip.Tensor(xh, allow_grad=True), hip.Tensor(yh, allow_grad=True)
+    mode = {"kind": 0}
+
+    def step():
+        x.grad = None
+        y.grad = None
+        loss = hip.sum((hip.sin(x) * y) ** 2) if mode["kind"] == 0 else hip.sum(hip.cos(x) * y)
+        loss.backward()
+        return {"x": x, "y": y}
+
+    gx0, gy0 = _cfg3_expected(xh, yh)
+    with SweepCache(hip, validate_every=3) as cache:
+        for i in range(6):
+            out = cache.run(step)
+            np.testing.assert_allclose(out["x"].grad.as_numpy(), gx0, rtol=2e-5, atol=1e-6)
+            np.testing.assert_allclose(out["y"].grad.as_numpy(), gy0, rtol=2e-5, atol=1e-6)
+        assert cache.stats["captured"] == 1 and cache.stats["replayed"] >= 2 and cache.stats["invalidated"] == 0
+        # new inputs written INTO the resident tensors are picked up by the replays
+        x2 = rng.standard_normal(n, dtype=np.float32)
+        x._data[...] = nd.asarray(x2)
+        out = cache.run(step)
+        np.testing.assert_allclose(out["x"].grad.as_numpy(), _cfg3_expected(x2, yh)[0], rtol=2e-5, atol=1e-6)
+        # the graph changes: replays still run the OLD structure until the next validation run...
+        mode["kind"] = 1
+        seen_new = False
+        for i in range(8):
+            out = cache.run(step)
+            got = out["x"].grad.as_numpy()
+            new = np.allclose(got, -np.sin(x2) * yh, rtol=2e-5, atol=1e-6)
+            old = np.allclose(got, _cfg3_expected(x2, yh)[0], rtol=2e-5, atol=1e-6)
+            assert new or old
+            if seen_new:
+                assert new, "after the re-capture every run must follow the new structure"
+            seen_new = seen_new or new
+        assert seen_new and cache.stats["invalidated"] == 1 and cache.stats["captured"] == 2
