@@ -361,7 +361,7 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
 }
 
 // (128x128x32, 8-wave 256x128 and 256x256 tiles were measured and dropped: profiles/r1_gemm_tile_ab.log)
-enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_256x128x16_S0, CFG_128x64x16_S0, CFG_256x256x32, CFG_128x128x32, CFG_128x64x32, CFG_COUNT };
+enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_256x256x32, CFG_128x128x32, CFG_128x64x32, CFG_COUNT };
 
 static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged) {
   if (const char *e = getenv("MDHIP_GEMM_CFG")) {  // experiments only
@@ -404,8 +404,6 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
     case CFG_64x64x16: return launch_cfg<64, 64, 16, 2, 2, A_KC, B_KC, 0>(ga, batch, edge);   // (2 MFMAs per step: nothing to interleave with; measured 6 % slower)
     case CFG_128x64x16: return launch_cfg<128, 64, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
     case CFG_256x128x16: return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
-    case CFG_256x128x16_S0: return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC, 0>(ga, batch, edge);
-    case CFG_128x64x16_S0: return launch_cfg<128, 64, 16, 2, 2, A_KC, B_KC, 0>(ga, batch, edge);
     // deeper k-tiles for the small tiles of the TN layout: a k-tile of a small tile is too short to cover the
     // global-load latency of the tile staged two ahead (2048^3 TN: 106 -> 117 TFLOP/s); the k-contiguous
     // layouts are held back by their transposing LDS stores instead and gain nothing from it

@@ -78,7 +78,10 @@ class SweepCache:
         simply a different entry: it runs eagerly, then captures its own graph;
       * a replay executes no Python, so it cannot see a change by itself: every `validate_every`-th call of a
         captured entry runs eagerly instead and compares hashes; on a mismatch the stale graph is destroyed.
-    A sweep that cannot be captured (a synchronising call inside it; the CPU test double) stays eager."""
+    A sweep that cannot be captured (a synchronising call inside it; the CPU test double) stays eager.
+    `step` should RETURN the arrays it produces (e.g. the gradient tensors): a replay rewrites those very arrays,
+    but it runs no Python, so attributes that the sweep rebinds (`x.grad = ...`) keep pointing at whatever the
+    last Python-executed run left there."""
 
     def __init__(self, md, validate_every: int = 0):
         self.md = md
@@ -87,6 +90,10 @@ class SweepCache:
         self._current = {}      # id(step) -> hash of its latest eager/capturing run
         self._calls = {}        # id(step) -> calls since the last eager run
         self.stats = {"eager": 0, "captured": 0, "replayed": 0, "invalidated": 0, "uncapturable": 0}
+
+    @staticmethod
+    def _lib_sync():
+        (_capi.current() or _capi.load()).sync()
 
     def _eager(self, step):
         with self.md.reuse_graph():
@@ -124,16 +131,19 @@ class SweepCache:
                 self.stats["eager"] += 1
                 self._current[sid] = h2
                 return out
-            if h2 != h:   # the structure moved between two consecutive runs: do not trust this capture
+            # (a capture only RECORDS the kernels: the sweep's results exist after the first launch of the graph)
+            if h2 != h:   # the structure moved between two consecutive runs: do not keep this capture
+                out = sweep.replay()
+                self._lib_sync()
                 sweep.close()
                 self._current[sid] = h2
                 self._entries.setdefault((sid, h2), {"seen": 1, "sweep": None, "failed": False})
                 self.stats["eager"] += 1
-                return sweep.outputs
+                return out
             entry["sweep"] = sweep
             self._calls[sid] = 0
             self.stats["captured"] += 1
-            return sweep.outputs
+            return sweep.replay()
         out, h2 = self._eager(step)
         self.stats["eager"] += 1
         self._current[sid] = h2

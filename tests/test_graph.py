@@ -156,26 +156,26 @@ def test_sweep_cache_replays_and_recaptures_changed_graph(engines):
         y.grad = None
         loss = hip.sum((hip.sin(x) * y) ** 2) if mode["kind"] == 0 else hip.sum(hip.cos(x) * y)
         loss.backward()
-        return {"x": x, "y": y}
+        return {"gx": x.grad, "gy": y.grad}   # the RESULT arrays (a replay rewrites them; it cannot rebind x.grad)
 
     gx0, gy0 = _cfg3_expected(xh, yh)
     with SweepCache(hip, validate_every=3) as cache:
         for i in range(6):
             out = cache.run(step)
-            np.testing.assert_allclose(out["x"].grad.as_numpy(), gx0, rtol=2e-5, atol=1e-6)
-            np.testing.assert_allclose(out["y"].grad.as_numpy(), gy0, rtol=2e-5, atol=1e-6)
+            np.testing.assert_allclose(out["gx"].as_numpy(), gx0, rtol=2e-5, atol=1e-6)
+            np.testing.assert_allclose(out["gy"].as_numpy(), gy0, rtol=2e-5, atol=1e-6)
         assert cache.stats["captured"] == 1 and cache.stats["replayed"] >= 2 and cache.stats["invalidated"] == 0
         # new inputs written INTO the resident tensors are picked up by the replays
         x2 = rng.standard_normal(n, dtype=np.float32)
         x._data[...] = nd.asarray(x2)
         out = cache.run(step)
-        np.testing.assert_allclose(out["x"].grad.as_numpy(), _cfg3_expected(x2, yh)[0], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(out["gx"].as_numpy(), _cfg3_expected(x2, yh)[0], rtol=2e-5, atol=1e-6)
         # the graph changes: replays still run the OLD structure until the next validation run...
         mode["kind"] = 1
         seen_new = False
         for i in range(8):
             out = cache.run(step)
-            got = out["x"].grad.as_numpy()
+            got = out["gx"].as_numpy()
             new = np.allclose(got, -np.sin(x2) * yh, rtol=2e-5, atol=1e-6)
             old = np.allclose(got, _cfg3_expected(x2, yh)[0], rtol=2e-5, atol=1e-6)
             assert new or old
