@@ -207,6 +207,16 @@ int mdhip_reduce(int op, const mdhip_array *x, const mdhip_array *out, uint32_t 
  * Arrays are passed 3-D (batch, rows, cols); batch stride 0 broadcasts.
  * f32 and f64 run on MFMA; other dtypes take the generic kernel. */
 int mdhip_matmul(const mdhip_array *a, const mdhip_array *b, const mdhip_array *c);
+/* GEMM with the elementwise tail and the reduction of BASELINE's MLP forward in its epilogue (lazy mode,
+ * minidiff_amd/ndarray.py recognises the pattern): for row-major float32 a (M x K), b (K x N), bias (N)
+ *     sum_out  = sum(where(a @ b + bias > 0, a @ b + bias, 0))       (0-d float32)
+ *     mask_out = (a @ b + bias > 0)                                  (M x N numpy.bool_, C-contiguous)
+ * in ONE pass: the pre-activation is never written; the mask is what the backward pass needs of it
+ * (reference call pattern: minidiff/ops/definitions.py:487-492 matmul, :424-427 add, :468-471 greater,
+ * :555-559 where, :403-407 sum). Shapes that are not whole aligned tiles return MDHIP_EVALUE and the caller
+ * runs the plain product followed by the fused tail. Deterministic (per-block partials summed in order). */
+int mdhip_matmul_bias_relu_sum(const mdhip_array *a, const mdhip_array *b, const mdhip_array *bias,
+                               const mdhip_array *mask_out, const mdhip_array *sum_out);
 
 /* ======================= indexing (bit-exact) ============================= */
 /* Generalised gather/scatter over an "indexed view":

@@ -115,6 +115,7 @@ _PROTOTYPES = {
     "mdhip_arange": [_P(ArrayDesc), C.c_double, C.c_double],
     "mdhip_reduce": [C.c_int, _P(ArrayDesc), _P(ArrayDesc), C.c_uint32],
     "mdhip_matmul": [_P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc)],
+    "mdhip_matmul_bias_relu_sum": [_P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc)],
     "mdhip_gather": [_P(IndexPlan), C.c_void_p, C.c_int, _P(ArrayDesc)],
     "mdhip_scatter": [_P(IndexPlan), C.c_void_p, C.c_int, _P(ArrayDesc), C.c_int],
     "mdhip_nonzero_count": [_P(ArrayDesc), _P(C.c_int64)],

@@ -478,6 +478,17 @@ static int eval_multi(const mdhip_vm_program *progs, const mdhip_array *outs, in
 
 static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// A program whose operands are all dense or fully broadcast collapses to ONE axis; the column reductions want it as
+// (R rows, C columns) again: dense leaves advance C elements per row, broadcast ones none.
+static bool uncollapse_2d(const MdVmIter &it, int n_leaves, MdVmDev *D, int64_t R, int64_t C, int64_t *rows, int64_t *inner) {
+  if (it.ndim == 2 && *rows == R && *inner == C) return true;
+  if (it.ndim != 1 || *rows != 1 || *inner != R * C || (C & 3)) return false;
+  for (int l = 0; l < n_leaves; ++l) D->leaf[l].os = D->leaf[l].is ? C : 0;
+  *rows = R;
+  *inner = C;
+  return true;
+}
+
 // Sweep geometry for a (n_red x n_out) program: n_out = Q x 1024 elements (Q column vectors per lane of a 256-thread
 // block), a contiguous band of rows per block, one block per CU.
 static bool sweep_geometry(int64_t n_out, int64_t n_red, int *Q, int64_t *nblk, int64_t *chunk) {
@@ -485,7 +496,8 @@ static bool sweep_geometry(int64_t n_out, int64_t n_red, int *Q, int64_t *nblk, 
   const int64_t q = n_out / 1024;
   if (q != 1 && q != 2 && q != 4 && q != 8) return false;
   *Q = (int)q;
-  int64_t nb = MD_NUM_CUS;
+  static const int per_cu = [] { const char *e = getenv("MDHIP_SWEEP_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 1; return v == 2 ? 2 : 1; }();
+  int64_t nb = MD_NUM_CUS * per_cu;   // (the merge pass takes up to 512 partial rows)
   if (nb > n_red / 6) nb = n_red / 6;
   *chunk = (n_red + nb - 1) / nb;
   *nblk = (n_red + *chunk - 1) / *chunk;
@@ -507,11 +519,17 @@ static bool sweep_cols(const mdhip_vm_program *pr, int rop, const MdVmDev &D, in
   S.rop = rop;
   S.store = eval_out != nullptr;
   S.Q = Q;
-  int n_vec = 0;
   int64_t bytes = eval_out ? rows * inner * (int64_t)sizeof(T) : 0;
   for (int l = 0; l < pr->n_leaves; ++l)
-    if (S.leaf_mode[l] == jit::LM_VEC) { ++n_vec; bytes += rows * inner * (int64_t)md_dtype_size(pr->leaves[l].dtype); }
-  S.RU = n_vec * Q <= 4 ? 3 : (n_vec * Q <= 8 ? 2 : 1);  // ~12 x 16 B of loads in flight per lane
+    if (S.leaf_mode[l] == jit::LM_VEC) bytes += rows * inner * (int64_t)md_dtype_size(pr->leaves[l].dtype);
+  // rows per trip: ~192 B of loads in flight per lane (a bool leaf brings 4 B per column vector, a float leaf 16)
+  int64_t row_bytes = 0;
+  for (int l = 0; l < pr->n_leaves; ++l)
+    if (S.leaf_mode[l] == jit::LM_VEC) row_bytes += (int64_t)Q * 4 * (int64_t)md_dtype_size(pr->leaves[l].dtype);
+  static const int ru_env = [] { const char *e = getenv("MDHIP_SWEEP_RU"); return e ? atoi(e) : 0; }();
+  S.RU = ru_env > 0 ? ru_env : (row_bytes > 0 ? (int)((192 + row_bytes - 1) / row_bytes) : 1);
+  if (S.RU > 8) S.RU = 8;
+  if (S.RU < 1) S.RU = 1;
   S.nt = bytes > ((int64_t)320 << 20);
   hipFunction_t fn = jit::get(S);
   if (!fn) return false;
@@ -525,7 +543,8 @@ static bool sweep_cols(const mdhip_vm_program *pr, int rop, const MdVmDev &D, in
   A.outs[0] = eval_out;
   *status = jit::launch(fn, A, dim3((unsigned)nblk));
   if (*status == MDHIP_OK) {
-    k_reduce_cols_merge<R, T, T><<<(unsigned)((inner + 63) / 64), 1024, 0, md_stream()>>>((const T *)partial, inner, nblk, (T *)out->data);
+    if (nblk <= 256) k_reduce_cols_merge<R, T, T, 16><<<(unsigned)((inner + 63) / 64), 1024, 0, md_stream()>>>((const T *)partial, inner, nblk, (T *)out->data);
+    else k_reduce_cols_merge<R, T, T, 32><<<(unsigned)((inner + 63) / 64), 1024, 0, md_stream()>>>((const T *)partial, inner, nblk, (T *)out->data);
     *status = MD_LAUNCH_CHECK("vm_reduce(cols,sweep)");
   }
   mdhip_free(partial);
@@ -582,7 +601,7 @@ static int reduce_typed(const mdhip_vm_program *pr, int rop, const mdhip_array *
     return rc;
   }
   // reduce over axis 0 of a 2-D program that did NOT collapse to 1-D
-  if (nd == 2 && mask == 1u && it.ndim == 2 && shape_like->shape[0] == rows && shape_like->shape[1] == inner) {
+  if (nd == 2 && mask == 1u && uncollapse_2d(it, pr->n_leaves, &D, shape_like->shape[0], shape_like->shape[1], &rows, &inner)) {
     int status = MDHIP_OK;
     if (sweep_cols<R, T>(pr, rop, D, rows, inner, nullptr, out, &status)) return status;
     const int64_t n_out = inner, n_red = rows;
@@ -645,7 +664,8 @@ static int eval_reduce_cols_typed(const mdhip_vm_program *pr, int rop, const mdh
   MdVmDev D;
   to_dev(pr, &D);
   int64_t rows, inner;
-  if (!fast_geometry(it, pr->n_leaves, pr, true, &D, &rows, &inner) || it.ndim != 2 || rows != out_eval->shape[0] || inner != out_eval->shape[1])
+  if (!fast_geometry(it, pr->n_leaves, pr, true, &D, &rows, &inner) ||
+      !uncollapse_2d(it, pr->n_leaves, &D, out_eval->shape[0], out_eval->shape[1], &rows, &inner))
     return md_fail(MDHIP_EVALUE, "vm_eval_reduce_cols: geometry not supported");
   if (((uintptr_t)out_eval->data & 15) || ((uintptr_t)out_red->data & 15)) return md_fail(MDHIP_EVALUE, "vm_eval_reduce_cols: unaligned output");
   int status = MDHIP_OK;

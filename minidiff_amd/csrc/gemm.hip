@@ -52,6 +52,11 @@ struct GemmArgs {
   // split-K (gridDim.y > 1): block y multiplies k in [y*k_chunk, (y+1)*k_chunk) into its own
   // partial C (C + y*c_split), summed afterwards in split order by k_gemm_splitk_sum
   int64_t k_chunk, c_split;
+  // EPI = 1 (bias + relu epilogue): instead of C the kernel writes mask[m][n] = (acc + bias[n] > 0) and ONE partial
+  // sum of max(acc + bias[n], 0) per block (partial[blockIdx.x]); see mdhip_matmul_bias_relu_sum
+  const float *bias;
+  uint8_t *mask;
+  float *partial;
 };
 
 // Tile loaders for a ROWS x BK operand tile, NT threads, 16 B per thread per pass.
@@ -111,8 +116,11 @@ __device__ __forceinline__ void store_tile(float (*S)[ROWS + LDP], const f32x4 (
 // SPLITK is a separate instantiation on purpose: with the k-range arithmetic compiled into the plain
 // kernel its main loop came out instruction-for-instruction the same but with another register
 // assignment, and NN at 4096^3 dropped from 136.6 to 133.3 TFLOP/s (same-box A/B).
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool EDGE, bool SPLITK = false, int SCHED = 0>
-__global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_mfma(GemmArgs g) {
+// (two waves per SIMD is what the schedule counts on for every tile up to 256 x 128 — 128 accumulator registers. The epilogue
+// variants DECLARE it: left alone the bias/relu epilogue took 171 + 128 registers, one wave per SIMD, the whole product 5 % slower.
+// The plain kernel keeps its allocation — 61 VGPRs + 128 AGPRs — untouched.)
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool EDGE, bool SPLITK = false, int SCHED = 0, int EPI = 0>
+__global__ void __launch_bounds__(64 * WM * WN, (EPI != 0 && BM * BN <= 256 * 128) ? 2 : 1) k_gemm_f32_mfma(GemmArgs g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);  // MFMA tiles per wave along m / n
   __shared__ float As[2][BK][BM + LDP];
@@ -253,6 +261,73 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_mfma(GemmArgs g) {
     }
   }
 
+  if constexpr (EPI == 1) {
+    // fused epilogue of  loss = sum(where(X @ W + b > 0, X @ W + b, 0))  (reference call pattern: matmul
+    // definitions.py:487-492 -> add :424-427 -> greater :468-471 -> where :555-559 -> sum :403-407): the pre-activation
+    // never goes to memory; what the backward pass needs of it — the mask — does, as numpy.bool_ bytes.
+    // The accumulator layout gives a lane ONE column and 16 rows: written as it stands the mask would go out in 32-byte
+    // pieces of single bytes (measured: +106 us on the 8192 x 4096 x 4096 product). Instead the four lanes of a quad
+    // exchange their 16 result bits, each lane packs the 4 adjacent columns of 4 of the rows into one dword, the tile's
+    // mask is assembled in LDS (the operand buffers are free now; 16-byte groups XOR-swizzled by the row so that
+    // neither the dword writes nor the 16-byte reads conflict) and leaves as whole 128-byte rows.
+    static_assert(sizeof(As) >= (size_t)BM * BN, "the tile's mask must fit the A staging buffers");
+    static_assert(BN % 16 == 0, "16-byte mask vectors");
+    __syncthreads();
+    uint32_t *sm = reinterpret_cast<uint32_t *>(&As[0][0][0]);
+    constexpr int RW = BN / 4;   // dwords per mask row of the tile
+    constexpr int GX = (BN / 16) < 8 ? (BN / 16) : 8;   // 16-byte groups per row that take part in the swizzle
+    float lsum = 0.0f;
+    const int q = l32 >> 2, jq = l32 & 3;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) {
+        const int lcol = wn * (WTN * 32) + j * 32 + l32;
+        const float bv = g.bias[n0 + lcol];
+        uint32_t bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float z = acc[i][j][r] + bv;
+          const bool on = z > 0.0f;
+          lsum += on ? z : 0.0f;
+          bits |= (uint32_t)on << r;
+        }
+        uint32_t qb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) qb[k] = (uint32_t)__shfl((int)bits, (lane & ~3) + k, 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = jq + 4 * t;                                   // this lane packs accumulator rows r = jq, jq+4, jq+8, jq+12
+          const uint32_t d = ((qb[0] >> r) & 1u) | (((qb[1] >> r) & 1u) << 8) | (((qb[2] >> r) & 1u) << 16) | (((qb[3] >> r) & 1u) << 24);
+          const int lrow = wm * (WTM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int w = (wn * (WTN * 32) + j * 32) / 4 + q;          // dword index inside the mask row
+          const int grp = (w >> 2) ^ (lrow & (GX - 1));               // swizzled 16-byte group
+          sm[lrow * RW + (grp << 2) + (w & 3)] = d;
+        }
+      }
+    __syncthreads();
+    {
+      constexpr int VPR = BN / 16;  // 16-byte vectors per row
+      for (int v = threadIdx.x; v < BM * VPR; v += NT) {
+        const int lrow = v / VPR, gv = v - lrow * VPR;
+        const uint4 val = *reinterpret_cast<const uint4 *>(sm + lrow * RW + ((gv ^ (lrow & (GX - 1))) << 2));
+        *reinterpret_cast<uint4 *>(g.mask + (m0 + lrow) * g.N + n0 + gv * 16) = val;
+      }
+    }
+    // block sum in a fixed order: lanes by shuffle, then the waves through LDS
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) lsum += __shfl_down(lsum, d, 64);
+    float *red = &Bs[0][0][0];
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.0f;
+#pragma unroll
+      for (int w = 0; w < WM * WN; ++w) t += red[w];
+      g.partial[blockIdx.x] = t;
+    }
+    return;
+  }
   // C/D layout of the 32x32 accumulator: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < WTM; ++i)
@@ -306,7 +381,7 @@ __global__ void __launch_bounds__(MD_BLOCK) k_gemm_splitk_sum(const float *__res
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int SCHED = 0>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int SCHED = 0, int EPI = 0>
 static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
   ga.tiles_m = (int)((ga.M + BM - 1) / BM);
   ga.tiles_n = (int)((ga.N + BN - 1) / BN);
@@ -316,6 +391,12 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
     ga.super_h = (sh > 1 && ga.tiles_m >= sh && ga.tiles_n >= 8) ? sh : 0;
   }
   edge = edge || (ga.M % BM) || (ga.N % BN) || (ga.K % BK);
+  if constexpr (EPI != 0) {  // whole aligned tiles only; the caller falls back to the plain product otherwise
+    if (edge || batch != 1) return MDHIP_EVALUE;
+    dim3 grid((unsigned)(ga.tiles_m * ga.tiles_n), 1, 1);
+    k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, false, false, SCHED, EPI><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
+    return MD_LAUNCH_CHECK("matmul(f32 mfma, bias+relu epilogue)");
+  }
   // split-K: a grid that cannot give every CU a block (skinny M or N with a long K, e.g. a
   // 64 x 4096 batch through a 4096 x 4096 layer) is widened along k; >= 512 k per split
   const int64_t tiles = (int64_t)ga.tiles_m * ga.tiles_n * batch;
@@ -667,4 +748,73 @@ struct HipExec {
 
 extern "C" int mdhip_matmul(const mdhip_array *a, const mdhip_array *b, const mdhip_array *c) {
   return md_matmul_dispatch<HipExec>(a, b, c);
+}
+
+namespace {
+// sum of the per-block partials in index order (one block: deterministic)
+__global__ void __launch_bounds__(MD_BLOCK) k_gemm_epi_finish(const float *__restrict__ partial, int64_t n, float *__restrict__ out) {
+  __shared__ float sm[MD_BLOCK];
+  float acc = 0.0f;
+  for (int64_t i = threadIdx.x; i < n; i += MD_BLOCK) acc += partial[i];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int d = MD_BLOCK / 2; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) sm[threadIdx.x] += sm[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+template <int BM, int BN> static int launch_epi(GemmArgs ga) {
+  const int64_t tiles = ((ga.M + BM - 1) / BM) * ((ga.N + BN - 1) / BN);
+  void *partial = nullptr;
+  MD_TRY(mdhip_alloc((size_t)tiles * sizeof(float), &partial));
+  float *out = ga.partial;  // (the caller parked the 0-d result pointer here)
+  ga.partial = (float *)partial;
+  int rc = launch_cfg<BM, BN, 16, 2, 2, true, false, BM == 64 ? 0 : 1, 1>(ga, 1, false);
+  if (rc == MDHIP_OK) {
+    k_gemm_epi_finish<<<1, MD_BLOCK, 0, md_stream()>>>((const float *)partial, tiles, out);
+    rc = MD_LAUNCH_CHECK("matmul(bias+relu epilogue, finish)");
+  }
+  mdhip_free(partial);
+  return rc;
+}
+}  // namespace
+
+// sum_out = sum(where(a @ b + bias > 0, a @ b + bias, 0)) and mask_out = (a @ b + bias > 0), one GEMM pass with the
+// elementwise tail and the reduction in its epilogue. MDHIP_EVALUE ("not fused") for anything but row-major f32
+// a (M x K) and b (K x N) with whole aligned tiles: the caller then runs the plain product and the fused tail.
+extern "C" int mdhip_matmul_bias_relu_sum(const mdhip_array *a, const mdhip_array *b, const mdhip_array *bias,
+                                          const mdhip_array *mask_out, const mdhip_array *sum_out) {
+  MD_TRY(md_check_array(a, "matmul a"));
+  MD_TRY(md_check_array(b, "matmul b"));
+  MD_TRY(md_check_array(bias, "bias"));
+  MD_TRY(md_check_array(mask_out, "mask"));
+  MD_TRY(md_check_array(sum_out, "sum"));
+  if (a->dtype != MDHIP_F32 || b->dtype != MDHIP_F32 || bias->dtype != MDHIP_F32 || sum_out->dtype != MDHIP_F32 || mask_out->dtype != MDHIP_BOOL)
+    return md_fail(MDHIP_ETYPE, "matmul_bias_relu_sum: float32 operands, bool mask, float32 sum");
+  if (a->ndim != 2 || b->ndim != 2 || mask_out->ndim != 2 || bias->ndim != 1)
+    return md_fail(MDHIP_EVALUE, "matmul_bias_relu_sum: 2-D operands and mask, 1-D bias");
+  const int64_t M = a->shape[0], K = a->shape[1], N = b->shape[1];
+  if (b->shape[0] != K || bias->shape[0] != N || mask_out->shape[0] != M || mask_out->shape[1] != N)
+    return md_fail(MDHIP_EVALUE, "matmul_bias_relu_sum: shapes do not agree");
+  const bool row_major = a->strides[1] == 1 && b->strides[1] == 1 && bias->strides[0] == 1 && mask_out->strides[1] == 1 && mask_out->strides[0] == N;
+  auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+  if (!row_major || !al16(a->data) || !al16(b->data) || (a->strides[0] & 3) || (b->strides[0] & 3) || K < 16 || (K % 16))
+    return md_fail(MDHIP_EVALUE, "matmul_bias_relu_sum: layout not covered by the fused kernel");
+  GemmArgs ga{};
+  ga.A = (const float *)a->data; ga.B = (const float *)b->data; ga.C = nullptr;
+  ga.M = M; ga.N = N; ga.K = K;
+  ga.a_ms = a->strides[0]; ga.a_ks = 1; ga.b_ks = b->strides[0]; ga.b_ns = 1;
+  ga.c_ms = N; ga.c_ns = 1;
+  ga.bias = (const float *)bias->data;
+  ga.mask = (uint8_t *)mask_out->data;
+  ga.partial = (float *)sum_out->data;
+  // the plain kernel's tile choice, restricted to the tiles that divide the problem
+  const int cfg = pick_cfg(ga, 1, false);
+  if ((cfg == CFG_256x128x16 || cfg == CFG_256x256x32) && M % 256 == 0 && N % 128 == 0) return launch_epi<256, 128>(ga);
+  if (M % 128 == 0 && N % 128 == 0 && (cfg == CFG_128x128x16 || cfg == CFG_128x128x32 || cfg == CFG_256x128x16)) return launch_epi<128, 128>(ga);
+  if (M % 128 == 0 && N % 64 == 0 && cfg != CFG_64x64x16) return launch_epi<128, 64>(ga);
+  if (M % 64 == 0 && N % 64 == 0) return launch_epi<64, 64>(ga);
+  return md_fail(MDHIP_EVALUE, "matmul_bias_relu_sum: shape not covered by the fused kernel");
 }

@@ -25,7 +25,7 @@ from __future__ import annotations
 from . import _capi
 from ._capi import VM_BINARY, VM_PUSH, VM_SRC_CONST, VM_SRC_LEAF, VM_SRC_STACK, VM_UNARY, VM_WHERE, vm_ctrl
 
-LEAF, CONST, UNARY, BINARY, WHERE = range(5)
+LEAF, CONST, UNARY, BINARY, WHERE, GEMM = range(6)
 MAX_INSTR, MAX_LEAVES, MAX_DEPTH = 44, 8, 4
 
 
@@ -33,11 +33,12 @@ class Expr:
     """Node of a pending expression. `cdt` is the program's float type code (F32/F64);
     `n` / `depth` are the instruction count and stack need of its emitted form."""
 
-    __slots__ = ("kind", "code", "args", "n", "depth", "leaves", "cdt")
+    __slots__ = ("kind", "code", "args", "n", "depth", "leaves", "cdt", "owner")
 
     def __init__(self, kind, code, args, n, depth, leaves, cdt):
         self.kind, self.code, self.args = kind, code, args
         self.n, self.depth, self.leaves, self.cdt = n, depth, leaves, cdt
+        self.owner = None  # weakref to the pending DeviceArray this node is the value of (set by DeviceArray._pending)
 
 
 def leaf(arr, cdt):
@@ -46,6 +47,13 @@ def leaf(arr, cdt):
 
 def const(value, cdt):
     return Expr(CONST, 0, float(value), 1, 1, {}, cdt)
+
+
+def gemm(a, b, cdt):
+    """A deferred matrix product a @ b (both concrete 2-D arrays). Not an interpreter instruction: the array that
+    carries it materialises through the GEMM kernel, and enters elementwise programs as a LEAF — which lets the
+    reduction of `where(a @ b + bias > 0, a @ b + bias, 0)` be recognised and run in the GEMM's epilogue."""
+    return Expr(GEMM, 0, (a, b), 1, 1, {}, cdt)
 
 
 def _simple(e) -> bool:

@@ -48,7 +48,7 @@ def lazy_enabled() -> bool:
 
 
 # launches issued for pending expressions (tests assert that fusion really happened)
-FUSION_STATS = {"vm_eval": 0, "vm_reduce": 0, "vm_eval_multi": 0, "vm_eval_reduce_cols": 0, "deferred_cols": 0}
+FUSION_STATS = {"vm_eval": 0, "vm_reduce": 0, "vm_eval_multi": 0, "vm_eval_reduce_cols": 0, "deferred_cols": 0, "gemm_deferred": 0, "gemm_epilogue": 0}
 
 _DTYPE_CODES = {
     np.dtype(np.bool_): _capi.BOOL,
@@ -178,7 +178,7 @@ def normalize_axes(axis, ndim) -> tuple:
 
 
 class DeviceArray:
-    __slots__ = ("_buf", "_offset", "shape", "_strides", "dtype", "_code", "_expr", "_cdesc", "_tasks", "__weakref__")
+    __slots__ = ("_buf", "_offset", "shape", "_strides", "dtype", "_code", "_expr", "_cdesc", "_tasks", "_dependents", "__weakref__")
     __array_priority__ = 1000.0
     __hash__ = None
 
@@ -192,24 +192,53 @@ class DeviceArray:
         self._expr = None  # pending expression (lazy mode); _buf is None until materialised
         self._cdesc = None  # own-shape C descriptor, built once (geometry and block never change)
         self._tasks = None  # weakrefs to deferred reductions of this pending expression (_ColsTask)
+        self._dependents = None  # pending arrays that took THIS pending product as a leaf before it had a block
 
     # ---- lazy evaluation -----------------------------------------------------
     @staticmethod
     def _pending(expr, shape, dtype) -> "DeviceArray":
         arr = DeviceArray(None, 0, shape, _c_strides(shape), dtype)
         arr._expr = expr
-        key = id(arr)
+        expr.owner = weakref.ref(arr)
         for leaf in expr.leaves.values():
             b = leaf._buf
-            if b.deps is None:
-                b.deps = {}
-            deps = b.deps
-            deps[key] = weakref.ref(arr, lambda _r, k=key, d=deps: d.pop(k, None))  # (arrays are unhashable)
+            if b is None:  # a deferred matrix product: it registers this reader once it has a block
+                if leaf._dependents is None:
+                    leaf._dependents = []
+                leaf._dependents.append(weakref.ref(arr))
+                continue
+            _register_reader(b, arr)
+        return arr
+
+    @staticmethod
+    def _pending_gemm(a, b, shape, dtype, cdt) -> "DeviceArray":
+        """a @ b, not launched yet (lazy mode). Operands are concrete; in-place writes into them flush the product first."""
+        arr = DeviceArray(None, 0, shape, _c_strides(shape), dtype)
+        arr._expr = _lz.gemm(a, b, cdt)
+        arr._expr.owner = weakref.ref(arr)
+        for x in (a, b):
+            _register_reader(x._buf, arr)
         return arr
 
     def _materialize(self):
         e = self._expr
         if e is None:
+            return
+        if e.kind == _lz.GEMM:
+            a, b = e.args
+            self._buf = _Buffer(_prod(self.shape) * self.dtype.itemsize)
+            self._expr = None
+            try:
+                _gemm_into(a, b, self)
+            except BaseException:
+                self._buf, self._expr, self._cdesc = None, e, None
+                raise
+            FUSION_STATS["gemm_deferred"] += 1
+            deps, self._dependents = self._dependents, None
+            for r in deps or ():
+                d = r()
+                if d is not None and d._expr is not None:
+                    _register_reader(self._buf, d)
             return
         prog, keep = _lz.build_program(e, self.shape)
         self._buf = _Buffer(_prod(self.shape) * self.dtype.itemsize)
@@ -748,11 +777,21 @@ def _before_write(arr: "DeviceArray"):
                 d._materialize()
 
 
+def _register_reader(buf, arr):
+    """`arr` (pending) reads `buf`: an in-place write into that block must evaluate it first (_before_write)."""
+    if buf.deps is None:
+        buf.deps = {}
+    deps, key = buf.deps, id(arr)
+    deps[key] = weakref.ref(arr, lambda _r, k=key, d=deps: d.pop(k, None))  # (arrays are unhashable)
+
+
 def _as_expr(x, cdt):
     """operand -> expression node of a program computing in float type `cdt`."""
     if isinstance(x, DeviceArray):
         e = x._expr
         if e is not None:
+            if e.kind == _lz.GEMM:
+                return _lz.leaf(x, cdt)   # a deferred product is a leaf of elementwise programs
             if e.cdt == cdt:
                 return e
             x._materialize()
@@ -772,7 +811,7 @@ def _lazy_node(kind, code, operands, cdt, shape, odt):
             return DeviceArray._pending(e, shape, odt)
         big = None
         for x in operands:
-            if isinstance(x, DeviceArray) and x._expr is not None and (big is None or x._expr.n > big._expr.n):
+            if isinstance(x, DeviceArray) and x._expr is not None and x._expr.kind != _lz.GEMM and (big is None or x._expr.n > big._expr.n):
                 big = x
         if big is None:
             return None
@@ -1353,12 +1392,18 @@ def _fused_reduce(code, a, mask, kshape, out_dtype):
     """reduce(pending expression) in one pass: full reductions and the axis-0
     reduce-to-shape of a 2-D expression; None -> caller materialises and reduces."""
     e = a._expr
+    if e.kind == _lz.GEMM:
+        return None
     if code not in (_capi.R_SUM, _capi.R_PROD, _capi.R_MAX, _capi.R_MIN):
         return None
     if _FLOAT_DT.get(out_dtype) != e.cdt or a.dtype != out_dtype or a.size == 0:
         return None
     nd = a.ndim
     full = mask == (1 << nd) - 1
+    if full and code == _capi.R_SUM and e.kind == _lz.WHERE:
+        res = _gemm_epilogue_sum(e, a, kshape, out_dtype)
+        if res is not None:
+            return res
     cols = nd == 2 and mask == 1 and a.shape[0] > 1 and a.shape[1] > 1 and a.shape[1] % 4 == 0
     if not (full or cols):
         return None
@@ -1382,6 +1427,50 @@ def _fused_reduce(code, a, mask, kshape, out_dtype):
 
 
 _DEFER_COLS_MIN = 1 << 18
+
+
+def _gemm_epilogue_sum(e, a, kshape, out_dtype):
+    """sum(where(P + bias > 0, P + bias, 0)) with P a deferred matrix product X @ W and bias a row vector — the forward of
+    BASELINE's MLP config as the untouched tape issues it (matmul, add, greater, where, sum). Runs as ONE GEMM whose
+    epilogue adds the bias, accumulates the relu sum and writes the mask (mdhip_matmul_bias_relu_sum): the 128 MiB
+    pre-activation never exists; the pending `greater` array — what the backward pass reads — becomes that mask.
+    None: the expression is something else, or the shape is not covered (the caller runs the general path)."""
+    c, t, f = e.args
+    if f.kind != _lz.CONST or f.args != 0.0 or c.kind != _lz.BINARY or c.code != _capi.B_GT:
+        return None
+    if c.args[0] is not t or c.args[1].kind != _lz.CONST or c.args[1].args != 0.0:
+        return None
+    if t.kind != _lz.BINARY or t.code != _capi.B_ADD:
+        return None
+    p, q = t.args
+    if p.kind != _lz.LEAF or q.kind != _lz.LEAF:
+        return None
+    if p.args._expr is None or p.args._expr.kind != _lz.GEMM:
+        p, q = q, p
+    prod, bias = p.args, q.args
+    if prod._expr is None or prod._expr.kind != _lz.GEMM or bias._expr is not None:
+        return None
+    if prod.shape != a.shape or bias.dtype != np.float32 or out_dtype != np.float32:
+        return None
+    M, N = prod.shape
+    if bias.shape == (1, N):
+        bias = bias._view(bias._offset, (N,), bias._strides[1:])
+    if bias.shape != (N,) or bias._strides != (1,):
+        return None
+    x, w = prod._expr.args
+    if x._strides[-1] != 1 or w._strides[-1] != 1:
+        return None
+    mask = DeviceArray.empty((M, N), np.bool_)
+    res = DeviceArray.empty(kshape, out_dtype)
+    try:
+        _lib().matmul_bias_relu_sum(x.desc(), w.desc(), bias.desc(), mask.desc(), res.desc())
+    except ValueError:
+        return None
+    FUSION_STATS["gemm_epilogue"] += 1
+    owner = c.owner() if c.owner is not None else None
+    if owner is not None and owner._expr is c and owner.dtype == np.bool_ and owner.shape == (M, N):
+        owner._buf, owner._expr, owner._cdesc = mask._buf, None, None   # `z > 0` is now in memory
+    return res
 
 
 def _reduce_pending(e, shape, code, mask, res) -> py_bool:
@@ -1575,6 +1664,12 @@ def matmul(a, b, out=None, **_):
             f"matmul: Input operand 1 has a mismatch in its core dimension 0, with gufunc signature (n?,k),(k,m?)->(n?,m?) (size {b.shape[-2]} is different from {a.shape[-1]})")
     batch = _broadcast_shapes(a.shape[:-2], b.shape[:-2])
     M, N = a.shape[-2], b.shape[-1]
+    if _LAZY and out is None and not batch and not a_vec and not b_vec and odt == np.float32 and a.shape[-1] > 0 and M * N > 0:
+        # deferred: the product may end up in the epilogue-fused form (_fused_reduce), otherwise it runs
+        # unchanged the moment anything needs its bytes
+        a.materialize()
+        b.materialize()
+        return DeviceArray._pending_gemm(a, b, (M, N), odt, _capi.F32)
     if out is not None:
         if not isinstance(out, DeviceArray) or a_vec or b_vec or out.shape != batch + (M, N) or out.dtype != odt or not out.is_c_contiguous:
             raise ValueError("matmul: out must be a C-contiguous DeviceArray with the shape and dtype of the result")
@@ -1600,6 +1695,15 @@ def matmul(a, b, out=None, **_):
         shp = batch + (M,)
         return res._view(res._offset, shp, _c_strides(shp))
     return res
+
+
+def _gemm_into(a, b, res):
+    """res[...] = a @ b for 2-D operands (the launch of a deferred product)."""
+    M, N = res.shape
+    a3 = a._view(a._offset, (1,) + a.shape, (0,) + a._strides)
+    b3 = b._view(b._offset, (1,) + b.shape, (0,) + b._strides)
+    c3 = res._view(res._offset, (1, M, N), (M * N, N, 1))
+    _lib().matmul(a3.desc(), b3.desc(), c3.desc())
 
 
 def _unalias_out(out, *operands):
@@ -2252,7 +2356,7 @@ def materialize_many(arrays):
             pending.append(a)
     groups = {}
     for a in pending:
-        if a.size and a.dtype in _FLOAT_DT and _FLOAT_DT[a.dtype] == a._expr.cdt and not a._tasks:  # (owed reductions ride on a single evaluation)
+        if a._expr.kind != _lz.GEMM and a.size and a.dtype in _FLOAT_DT and _FLOAT_DT[a.dtype] == a._expr.cdt and not a._tasks:  # (owed reductions ride on a single evaluation)
             groups.setdefault((a.shape, a._expr.cdt), []).append(a)
     for group in groups.values():
         while len(group) >= 2:

@@ -217,6 +217,37 @@ int mdhip_reduce(int op, const mdhip_array *x, const mdhip_array *out, uint32_t 
 int mdhip_matmul(const mdhip_array *a, const mdhip_array *b, const mdhip_array *c) {
   return md_matmul_dispatch<HostExec>(a, b, c);
 }
+// fused GEMM + bias + relu-sum + mask: plain loops here (k-ordered float fma chain per element, as the MFMA kernel)
+int mdhip_matmul_bias_relu_sum(const mdhip_array *a, const mdhip_array *b, const mdhip_array *bias,
+                               const mdhip_array *mask_out, const mdhip_array *sum_out) {
+  MD_TRY(md_check_array(a, "matmul a"));
+  MD_TRY(md_check_array(b, "matmul b"));
+  MD_TRY(md_check_array(bias, "bias"));
+  MD_TRY(md_check_array(mask_out, "mask"));
+  MD_TRY(md_check_array(sum_out, "sum"));
+  if (a->dtype != MDHIP_F32 || b->dtype != MDHIP_F32 || bias->dtype != MDHIP_F32 || sum_out->dtype != MDHIP_F32 || mask_out->dtype != MDHIP_BOOL)
+    return md_fail(MDHIP_ETYPE, "matmul_bias_relu_sum: float32 operands, bool mask, float32 sum");
+  if (a->ndim != 2 || b->ndim != 2 || mask_out->ndim != 2 || bias->ndim != 1)
+    return md_fail(MDHIP_EVALUE, "matmul_bias_relu_sum: 2-D operands and mask, 1-D bias");
+  const int64_t M = a->shape[0], K = a->shape[1], N = b->shape[1];
+  if (b->shape[0] != K || bias->shape[0] != N || mask_out->shape[0] != M || mask_out->shape[1] != N)
+    return md_fail(MDHIP_EVALUE, "matmul_bias_relu_sum: shapes do not agree");
+  if ((M % 64) || (N % 64) || (K % 16))   // (the double keeps the product's notion of "covered", so that both paths get exercised)
+    return md_fail(MDHIP_EVALUE, "matmul_bias_relu_sum: shape not covered by the fused kernel");
+  const float *A = (const float *)a->data, *B = (const float *)b->data, *bv = (const float *)bias->data;
+  uint8_t *mk = (uint8_t *)mask_out->data;
+  float total = 0.0f;
+  for (int64_t m = 0; m < M; ++m)
+    for (int64_t n = 0; n < N; ++n) {
+      float acc = 0.0f;
+      for (int64_t k = 0; k < K; ++k) acc = fmaf(A[m * a->strides[0] + k * a->strides[1]], B[k * b->strides[0] + n * b->strides[1]], acc);
+      const float z = acc + bv[n * bias->strides[0]];
+      mk[m * mask_out->strides[0] + n * mask_out->strides[1]] = z > 0.0f;
+      total += z > 0.0f ? z : 0.0f;
+    }
+  ((float *)sum_out->data)[0] = total;
+  return MDHIP_OK;
+}
 
 int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const mdhip_array *out) {
   MD_TRY(md_check_plan(pl));
@@ -324,7 +355,9 @@ static int host_vm_reduce(const mdhip_vm_program *pr, const mdhip_array *shape_l
   }
   if (nd == 2 && mask == 1u) {
     const int64_t rows = shape_like->shape[0], cols = shape_like->shape[1];
-    if (it.ndim != 2 || it.shape[0] != rows || it.shape[1] != cols || (cols & 3))
+    // (a program whose operands are all dense or fully broadcast collapses to 1-D: the linear index still is r*cols + c)
+    const bool flat = it.ndim == 1 && it.shape[0] == rows * cols;
+    if (!(flat || (it.ndim == 2 && it.shape[0] == rows && it.shape[1] == cols)) || (cols & 3))
       return md_fail(MDHIP_EVALUE, "vm_reduce: geometry not supported");
     for (int64_t c = 0; c < cols; ++c) {
       T acc = R::template identity<T>();

@@ -2,6 +2,8 @@
 fused results equal the eager ones (same per-element functors), pending
 expressions survive in-place writes to their leaves, programs that outgrow the
 interpreter are split, and the fused launches really replace the eager ones."""
+import os
+
 import numpy as np
 import pytest
 
@@ -318,3 +320,83 @@ def _sincos_hoist(nd, on_gpu, want_gpu):
 def test_sincos_hoist_cpu(lazy_nd, on_gpu): _sincos_hoist(lazy_nd, on_gpu, False)
 @gpu
 def test_sincos_hoist_gpu(lazy_nd, on_gpu): _sincos_hoist(lazy_nd, on_gpu, True)
+
+
+# ---- GEMM epilogue fusion: matmul is deferred in lazy mode; sum(where(X@W+b > 0, X@W+b, 0)) runs as ONE GEMM whose
+# ---- epilogue adds the bias, accumulates the relu sum and writes the mask the backward pass needs
+def _gemm_epilogue(nd, on_gpu, want_gpu, engines):
+    if want_gpu != on_gpu:
+        pytest.skip("other twin")
+    from minidiff_amd import workloads
+    rng = np.random.default_rng(21)
+    M, K, N = 256, 64, 128
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((K, N)) / 8).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    dX, dW, db = nd.asarray(X), nd.asarray(W), nd.asarray(b)
+    z_ref = X.astype(np.float64) @ W + b
+    s0 = dict(nd.FUSION_STATS)
+    p = nd.matmul(dX, dW)
+    assert p._expr is not None and p._buf is None, "matmul must be deferred in lazy mode"
+    z = nd.add(p, db)
+    m = nd.greater(z, 0)
+    loss = nd.sum(nd.where(m, z, 0))
+    assert nd.FUSION_STATS["gemm_epilogue"] - s0["gemm_epilogue"] == 1
+    assert nd.FUSION_STATS["gemm_deferred"] == s0["gemm_deferred"] and nd.FUSION_STATS["vm_reduce"] == s0["vm_reduce"]
+    assert m._expr is None and m._buf is not None and p._buf is None      # the mask exists, the product was never written
+    _close(loss.get(), np.where(z_ref > 0, z_ref, 0).sum(), 1e-5)
+    near = np.abs(z_ref) < 1e-5 * np.abs(z_ref).max()                      # entries within rounding of 0 may flip
+    assert np.array_equal(m.get()[~near], (z_ref > 0)[~near])
+    # the product is still available to anybody who asks (plain GEMM then)
+    _close(p.get(), X.astype(np.float64) @ W, 2e-6)
+    assert nd.FUSION_STATS["gemm_deferred"] - s0["gemm_deferred"] == 1
+    # commuted operands of the add are recognised too; a shape outside the fused kernel's tiles takes the general path
+    s0 = dict(nd.FUSION_STATS)
+    z2 = nd.add(db, nd.matmul(dX, dW))
+    l2 = nd.sum(nd.where(nd.greater(z2, 0), z2, 0))
+    assert nd.FUSION_STATS["gemm_epilogue"] - s0["gemm_epilogue"] == 1
+    _close(l2.get(), np.where(z_ref > 0, z_ref, 0).sum(), 1e-5)
+    s0 = dict(nd.FUSION_STATS)
+    Xo = nd.asarray(X[:100])
+    z3 = nd.add(nd.matmul(Xo, dW), db)
+    l3 = nd.sum(nd.where(nd.greater(z3, 0), z3, 0))
+    assert nd.FUSION_STATS["gemm_epilogue"] == s0["gemm_epilogue"] and nd.FUSION_STATS["gemm_deferred"] - s0["gemm_deferred"] == 1
+    _close(l3.get(), np.where(z_ref[:100] > 0, z_ref[:100], 0).sum(), 1e-5)
+    # another tail (no relu) is not this pattern
+    s0 = dict(nd.FUSION_STATS)
+    l4 = nd.sum(nd.multiply(nd.add(nd.matmul(dX, dW), db), 2.0))
+    assert nd.FUSION_STATS["gemm_epilogue"] == s0["gemm_epilogue"]
+    _close(l4.get(), (2 * z_ref).sum(), 1e-5)
+    # a deferred product sees its operands as they were at the call: in-place writes flush it first
+    dX2 = nd.asarray(X.copy())
+    p2 = nd.matmul(dX2, dW)
+    dX2 *= 0.0
+    _close(p2.get(), X.astype(np.float64) @ W, 2e-6)
+    # ... and an expression that took the pending product as a leaf is flushed before the product is overwritten
+    p3 = nd.matmul(dX, dW)
+    e3 = nd.multiply(p3, 3.0)
+    p3 += 1.0
+    _close(e3.get(), 3 * (X.astype(np.float64) @ W), 2e-6)
+    _close(p3.get(), X.astype(np.float64) @ W + 1, 2e-6)
+
+    # the whole cfg4 sweep through the tape: forward in the GEMM epilogue, backward from the mask
+    hip, oracle = engines
+    s0 = dict(nd.FUSION_STATS)
+    st, step = workloads.make_cfg4(hip, batch=512, d_in=128, d_out=1024)
+    out = step()
+    assert nd.FUSION_STATS["gemm_epilogue"] - s0["gemm_epilogue"] == 1
+    Xh, Wh, bh = st["X"].as_numpy(), st["W"].as_numpy(), st["b"].as_numpy()
+    zz = Xh.astype(np.float64) @ Wh + bh
+    mm = np.asarray(zz > 0)
+    _close(out["out"].as_numpy(), np.where(mm, zz, 0).sum(), 1e-5)
+    gW, gb = st["W"].grad.as_numpy(), st["b"].grad.as_numpy()
+    # gradients for the DEVICE's own mask would need the mask; near-zero pre-activations are ~1e-5 of the entries at most
+    expW, expb = Xh.astype(np.float64).T @ mm, mm.sum(axis=0, dtype=np.float64)
+    assert np.abs(gb - expb).max() <= 2 and np.abs(gW - expW).max() <= 2e-5 * np.abs(expW).max() + 8
+    if os.environ.get("MDHIP_JIT") != "0":
+        assert nd.FUSION_STATS["vm_eval_reduce_cols"] - s0["vm_eval_reduce_cols"] == 1   # g*mask + column sum: one pass over the MASK
+
+
+def test_gemm_epilogue_cpu(lazy_nd, on_gpu, engines): _gemm_epilogue(lazy_nd, on_gpu, False, engines)
+@gpu
+def test_gemm_epilogue_gpu(lazy_nd, on_gpu, engines): _gemm_epilogue(lazy_nd, on_gpu, True, engines)
