@@ -531,6 +531,11 @@ static bool sweep_cols(const mdhip_vm_program *pr, int rop, const MdVmDev &D, in
   if (S.RU > 8) S.RU = 8;
   if (S.RU < 1) S.RU = 1;
   S.nt = bytes > ((int64_t)320 << 20);
+  // the evaluated value of a one-pass eval + column reduce is a large write next to (often much smaller) reads, and its
+  // reader is whatever needed it in memory (cfg4: the weight-gradient GEMM, which is not bandwidth-bound): written around
+  // the caches the pass ran 32.9 -> 26.3 us on the cfg4 shape (128 MiB out, 32 MiB mask in), the GEMM behind it unchanged; MDHIP_SWEEP_NT_STORE=0 disables
+  static const int nt_store = [] { const char *e = getenv("MDHIP_SWEEP_NT_STORE"); return e ? atoi(e) : 1; }();
+  S.nt_store = nt_store && eval_out != nullptr && rows * inner * (int64_t)sizeof(T) >= ((int64_t)64 << 20);
   hipFunction_t fn = jit::get(S);
   if (!fn) return false;
   void *partial = nullptr;
