@@ -226,9 +226,10 @@ template <class F, class Tc, class To, class Tx, int MX, bool NT> struct UnaryBo
 };
 
 template <class F, class Tc, class To, class Ta, class Tb, int MA, int MB, bool NT> struct BinaryBody {
-  // three full streams (two operands + result): fewer resident waves ran faster — 400 MB multiply 203 us at 8 blocks
-  // per CU, 195 at 4, 190 at 2 (but one-operand kernels lose below 8: profiles/r2_ew_grid_ab.log)
-  static constexpr int kBlocksPerCU = (MA == OM_VEC && MB == OM_VEC) ? 4 : 8;
+  // fewer resident waves ran faster for the binary forms — 400 MB multiply(x, y) 203 us at 8 blocks per CU, 195 at 4,
+  // 190 at 2; cfg4 mask product (one streamed operand, f32 result) 31-35 -> 29.4-30.0, z > 0 28 -> 26 — while the unary
+  // kernels lose below 8 (sin 137 -> 142 us): profiles/r2_ew_grid_ab.log
+  static constexpr int kBlocksPerCU = 4;
   FastOp<Ta> a;
   FastOp<Tb> b;
   Tc sa, sb;

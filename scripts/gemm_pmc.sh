@@ -1,0 +1,19 @@
+#!/bin/bash
+# SQ counters of one GEMM shape/layout: where do the waves wait?  usage: gemm_pmc.sh TAG M K N LAYOUT(NN|NT|TN) [CFG]
+tag=$1; shift
+out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
+[ -n "$5" ] && export MDHIP_GEMM_CFG=$5
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS --output-format csv -d $out/pmc -- python3 scripts/gemm_one.py $1 $2 $3 $4 > $out/run.log 2>&1
+python3 - $out <<'PY'
+import csv,glob,sys,collections
+agg=collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(sys.argv[1]+'/pmc/**/*_counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'gemm' in r['Kernel_Name']:
+            agg[r['Kernel_Name'].split('(')[0][-60:]][r['Counter_Name']].append(float(r['Counter_Value']))
+for k,c in agg.items():
+    print(k)
+    wc=sum(c['SQ_WAVE_CYCLES'])/len(c['SQ_WAVE_CYCLES'])
+    for n,v in sorted(c.items()):
+        m=sum(v)/len(v); print("   %-28s %14.0f  %6.1f %% of wave cycles" % (n, m, 100*m/wc))
+PY
