@@ -14,7 +14,6 @@
 // atomics, no write races. Integer ADD uses atomics (exact in any order).
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "md_hip.h"
 
@@ -158,29 +157,28 @@ static int read_flag(int *dflag, int *host) {
 // whole rows: the plan's last axis is a contiguous run of the destination that no index array
 // varies along. Then the duplicates question is per ROW: destinations of two plan rows are
 // either identical or disjoint (checked on the host: every outer stride is a multiple of a
-// common g >= run length). The P row offsets are sorted stably (rocPRIM radix sort, so equal
+// common g >= run length). The P row offsets are sorted stably (the LSD radix sort below, so equal
 // destinations keep plan order) and each destination row is produced by ONE pass that applies
 // its contributions in that order: np.add.at's accumulation order / last-write-wins for SET,
 // O(P log P + P*L) whatever the multiplicities.
-constexpr uint64_t RUN_BIAS = 1ull << 62;
-__global__ void __launch_bounds__(MD_BLOCK) k_run_offsets(mdhip_index_plan pl, int64_t P, int64_t L, uint64_t *keys, int64_t *ids) {
+__global__ void __launch_bounds__(MD_BLOCK) k_run_offsets(mdhip_index_plan pl, int64_t P, int64_t L, int64_t lo, uint64_t *keys, int64_t *ids) {
   const int64_t gs = (int64_t)gridDim.x * blockDim.x;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gs) {
     int64_t pos[MDHIP_MAX_NDIM];
     bool oob = false;
-    keys[p] = (uint64_t)(md_plan_offset(pl, p * L, pos, &oob) + (int64_t)RUN_BIAS);
+    keys[p] = (uint64_t)(md_plan_offset(pl, p * L, pos, &oob) - lo);   // (key = offset relative to the smallest reachable one)
     ids[p] = p;
   }
 }
 template <class T, int MODE>
-__global__ void __launch_bounds__(MD_BLOCK) k_run_apply(mdhip_index_plan pl, int64_t P, int64_t L, const uint64_t *__restrict__ keys,
+__global__ void __launch_bounds__(MD_BLOCK) k_run_apply(mdhip_index_plan pl, int64_t P, int64_t L, int64_t lo, const uint64_t *__restrict__ keys,
                                                        const int64_t *__restrict__ ids, T *dst, ValDesc v, T s) {
   const int64_t gs = (int64_t)gridDim.x * blockDim.x, total = P * L;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
     const int64_t q = i / L, c = i - q * L;
     const uint64_t key = keys[q];
     if (q > 0 && keys[q - 1] == key) continue;  // not the first contribution of its destination row
-    T *d = dst + ((int64_t)(key - RUN_BIAS) + c);
+    T *d = dst + ((int64_t)key + lo + c);
     auto value = [&](int64_t p) -> T {
       if (v.is_scalar) return s;
       int64_t lin = p, vo = c * v.strides[pl.ndim - 1];
@@ -204,7 +202,7 @@ __global__ void __launch_bounds__(MD_BLOCK) k_run_apply(mdhip_index_plan pl, int
 }
 // the same with 16-B units when rows, destination and values are 16-B aligned
 template <class T, int MODE>
-__global__ void __launch_bounds__(MD_BLOCK) k_run_apply_vec(mdhip_index_plan pl, int64_t P, int64_t L, const uint64_t *__restrict__ keys,
+__global__ void __launch_bounds__(MD_BLOCK) k_run_apply_vec(mdhip_index_plan pl, int64_t P, int64_t L, int64_t lo, const uint64_t *__restrict__ keys,
                                                            const int64_t *__restrict__ ids, T *dst, ValDesc v, T s) {
   constexpr int V = 16 / sizeof(T);
   const int64_t Lv = L / V, gs = (int64_t)gridDim.x * blockDim.x, total = P * Lv;
@@ -212,7 +210,7 @@ __global__ void __launch_bounds__(MD_BLOCK) k_run_apply_vec(mdhip_index_plan pl,
     const int64_t q = i / Lv, c = (i - q * Lv) * V;
     const uint64_t key = keys[q];
     if (q > 0 && keys[q - 1] == key) continue;
-    MdVec<T, V> *d = reinterpret_cast<MdVec<T, V> *>(dst + ((int64_t)(key - RUN_BIAS) + c));
+    MdVec<T, V> *d = reinterpret_cast<MdVec<T, V> *>(dst + ((int64_t)key + lo + c));
     auto value = [&](int64_t p) -> MdVec<T, V> {
       MdVec<T, V> r;
       if (v.is_scalar) {
@@ -279,36 +277,183 @@ static bool run_geometry(const mdhip_index_plan *pl, int64_t *L, int64_t *P) {
   }
   for (int k = 0; k < pl->n_idx; ++k)
     if (pl->idx_extent[k] > 1) g = gcd64(g, pl->idx_mult[k]);
-  return (g == 0 || g >= *L) && *P < (1ll << 31);
+  return (g == 0 || g >= *L) && *P < (1ll << 27);  // (the sort keeps 256 counters per 2048 rows: 64 MiB at this bound)
 }
+// ---- stable LSD radix sort of (key, id) pairs: 8 bits per pass, as many passes as the keys have bits --------------
+// Pass = histogram per 2048-item tile -> exclusive scan of the [digit][tile] counts -> scatter. Stability inside a
+// tile: items are taken in 8 rounds of 256 (round-major = input order), the four waves of a round one after the other;
+// inside a wave a lane's rank among the lanes with the same digit comes from 8 ballots (one per digit bit).
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = MD_BLOCK * RS_ITEMS;
+
+__global__ void __launch_bounds__(MD_BLOCK) k_rs_hist(const uint64_t *__restrict__ keys, int64_t P, int shift, uint32_t *__restrict__ hist, int64_t nblk) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; ++r) {
+    const int64_t i = base + r * MD_BLOCK + threadIdx.x;
+    if (i < P) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  hist[(int64_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+// exclusive scan of n counters, three launches: per-chunk scan (2048 per block) + chunk totals, scan of the totals (one
+// block), add-back
+__global__ void __launch_bounds__(MD_BLOCK) k_rs_scan_chunks(uint32_t *__restrict__ a, int64_t n, uint32_t *__restrict__ totals) {
+  __shared__ uint32_t part[MD_BLOCK];
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)threadIdx.x * RS_ITEMS;
+  uint32_t v[RS_ITEMS], sum = 0;
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; ++j) {
+    v[j] = base + j < n ? a[base + j] : 0u;
+    sum += v[j];
+  }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < MD_BLOCK; d <<= 1) {  // inclusive Hillis-Steele over the 256 thread sums
+    const uint32_t t = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - sum;
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; ++j) {
+    if (base + j < n) a[base + j] = run;
+    run += v[j];
+  }
+  if (threadIdx.x == MD_BLOCK - 1) totals[blockIdx.x] = part[MD_BLOCK - 1];
+}
+__global__ void __launch_bounds__(MD_BLOCK) k_rs_scan_totals(uint32_t *__restrict__ totals, int64_t m) {
+  __shared__ uint32_t part[MD_BLOCK];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t c0 = 0; c0 < m; c0 += MD_BLOCK) {
+    const int64_t i = c0 + threadIdx.x;
+    const uint32_t v = i < m ? totals[i] : 0u;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < MD_BLOCK; d <<= 1) {
+      const uint32_t t = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < m) totals[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += part[MD_BLOCK - 1];
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(MD_BLOCK) k_rs_scan_add(uint32_t *__restrict__ a, int64_t n, const uint32_t *__restrict__ totals) {
+  const uint32_t off = totals[blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)threadIdx.x * RS_ITEMS;
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; ++j)
+    if (base + j < n) a[base + j] += off;
+}
+__global__ void __launch_bounds__(MD_BLOCK) k_rs_scatter(const uint64_t *__restrict__ kin, const int64_t *__restrict__ iin, uint64_t *__restrict__ kout,
+                                                        int64_t *__restrict__ iout, int64_t P, int shift, const uint32_t *__restrict__ offs, int64_t nblk) {
+  __shared__ uint32_t cnt[256];  // next output slot of every digit for this tile
+  cnt[threadIdx.x] = offs[(int64_t)threadIdx.x * nblk + blockIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+  for (int r = 0; r < RS_ITEMS; ++r) {
+    const int64_t i = base + r * MD_BLOCK + threadIdx.x;
+    const bool valid = i < P;
+    const uint64_t key = valid ? kin[i] : 0ull;
+    const int64_t id = valid ? iin[i] : 0;
+    const uint32_t digit = (uint32_t)(key >> shift) & 255u;
+    uint32_t pos = 0;
+    for (int w = 0; w < MD_BLOCK / 64; ++w) {
+      if (wave == w) {
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const uint64_t vote = __ballot((digit >> b) & 1u);
+          peers &= ((digit >> b) & 1u) ? vote : ~vote;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & below);
+        if (valid) {
+          pos = cnt[digit] + rank;                                        // every lane of the wave reads ...
+          if (rank == 0) cnt[digit] += (uint32_t)__popcll(peers);          // ... before the group's first lane advances the slot
+        }
+      }
+      __syncthreads();
+    }
+    if (valid) {
+      kout[pos] = key;
+      iout[pos] = id;
+    }
+  }
+}
+// keys/ids: two halves of 2P elements each (ping-pong); returns which half holds the sorted sequence
+static int radix_sort_pairs(uint64_t *keys, int64_t *ids, int64_t P, int key_bits, int *result_half) {
+  hipStream_t st = md_stream();
+  const int64_t nblk = (P + RS_TILE - 1) / RS_TILE;
+  const int64_t n = 256 * nblk, nchunks = (n + RS_TILE - 1) / RS_TILE;
+  void *hist = nullptr, *totals = nullptr;
+  MD_TRY(mdhip_alloc((size_t)n * 4, &hist));
+  int rc = mdhip_alloc((size_t)nchunks * 4, &totals);
+  int half = 0;
+  if (rc == MDHIP_OK) {
+    for (int shift = 0; shift < key_bits; shift += 8) {
+      uint64_t *kin = keys + half * P, *kout = keys + (half ^ 1) * P;
+      int64_t *iin = ids + half * P, *iout = ids + (half ^ 1) * P;
+      k_rs_hist<<<(unsigned)nblk, MD_BLOCK, 0, st>>>(kin, P, shift, (uint32_t *)hist, nblk);
+      k_rs_scan_chunks<<<(unsigned)nchunks, MD_BLOCK, 0, st>>>((uint32_t *)hist, n, (uint32_t *)totals);
+      k_rs_scan_totals<<<1, MD_BLOCK, 0, st>>>((uint32_t *)totals, nchunks);
+      k_rs_scan_add<<<(unsigned)nchunks, MD_BLOCK, 0, st>>>((uint32_t *)hist, n, (const uint32_t *)totals);
+      k_rs_scatter<<<(unsigned)nblk, MD_BLOCK, 0, st>>>(kin, iin, kout, iout, P, shift, (const uint32_t *)hist, nblk);
+      half ^= 1;
+    }
+    rc = MD_LAUNCH_CHECK("scatter(runs): radix sort");
+  }
+  if (totals) mdhip_free(totals);
+  mdhip_free(hist);
+  *result_half = half;
+  return rc;
+}
+
 template <class T, int MODE>
 static int scatter_runs(const mdhip_index_plan *pl, int64_t P, int64_t L, void *dst, const ValDesc &v, T s) {
   hipStream_t st = md_stream();
-  void *keys = nullptr, *ids = nullptr, *tmp = nullptr;
-  size_t tmp_bytes = 0;
-  uint64_t *k0 = nullptr;
-  int64_t *i0 = nullptr;
-  if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k0, i0, i0, (size_t)P, 0, 64, st) != hipSuccess)
-    return md_fail(MDHIP_ERUNTIME, "scatter(runs): sort sizing failed");
+  // key range from the plan (host side): offsets lie in [lo, hi]; keys are offset - lo, so the sort needs bits(hi - lo) only
+  int64_t lo = 0, hi = L - 1;
+  for (int d = 0; d < pl->ndim - 1; ++d) {
+    const int64_t e = (pl->shape[d] - 1) * pl->src_strides[d];
+    if (e < 0) lo += e; else hi += e;
+  }
+  for (int k = 0; k < pl->n_idx; ++k) {
+    const int64_t e = (pl->idx_extent[k] - 1) * pl->idx_mult[k];
+    if (e < 0) lo += e; else hi += e;
+  }
+  int key_bits = 1;
+  while (key_bits < 64 && ((uint64_t)(hi - lo) >> key_bits) != 0) ++key_bits;
+  void *keys = nullptr, *ids = nullptr;
   MD_TRY(mdhip_alloc((size_t)P * 16, &keys));
   int rc = mdhip_alloc((size_t)P * 16, &ids);
-  if (rc == MDHIP_OK) rc = mdhip_alloc(tmp_bytes ? tmp_bytes : 1, &tmp);
   if (rc == MDHIP_OK) {
-    uint64_t *kin = (uint64_t *)keys, *kout = kin + P;
-    int64_t *iin = (int64_t *)ids, *iout = iin + P;
-    k_run_offsets<<<md_grid_for(P), MD_BLOCK, 0, st>>>(*pl, P, L, kin, iin);
-    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, iin, iout, (size_t)P, 0, 64, st) != hipSuccess) {
-      (void)hipGetLastError();
-      rc = md_fail(MDHIP_ERUNTIME, "scatter(runs): sort failed");
-    } else {
+    uint64_t *kin = (uint64_t *)keys;
+    int64_t *iin = (int64_t *)ids;
+    k_run_offsets<<<md_grid_for(P), MD_BLOCK, 0, st>>>(*pl, P, L, lo, kin, iin);
+    int half = 0;
+    rc = radix_sort_pairs(kin, iin, P, key_bits, &half);
+    if (rc == MDHIP_OK) {
+      const uint64_t *kout = kin + half * P;
+      const int64_t *iout = iin + half * P;
       if (run_vectorisable<T>(pl, L, dst, v))
-        k_run_apply_vec<T, MODE><<<md_grid_for(P * (L / (16 / (int64_t)sizeof(T)))), MD_BLOCK, 0, st>>>(*pl, P, L, kout, iout, (T *)dst, v, s);
+        k_run_apply_vec<T, MODE><<<md_grid_for(P * (L / (16 / (int64_t)sizeof(T)))), MD_BLOCK, 0, st>>>(*pl, P, L, lo, kout, iout, (T *)dst, v, s);
       else
-        k_run_apply<T, MODE><<<md_grid_for(P * L), MD_BLOCK, 0, st>>>(*pl, P, L, kout, iout, (T *)dst, v, s);
+        k_run_apply<T, MODE><<<md_grid_for(P * L), MD_BLOCK, 0, st>>>(*pl, P, L, lo, kout, iout, (T *)dst, v, s);
       rc = MD_LAUNCH_CHECK("scatter(runs)");
     }
   }
-  if (tmp) mdhip_free(tmp);
   if (ids) mdhip_free(ids);
   mdhip_free(keys);
   return rc;

@@ -190,6 +190,28 @@ def _scatter():
         d = nd.asarray(t)
         nd.index_add(d, (slice(None), nd.asarray(i3)), nd.asarray(v3))
         assert np.array_equal(np.asarray(d), exp)
+    # many tiles of the stable radix sort behind the row-granular path (index.hip: 2048 rows per tile, 8 bits per pass):
+    # 300k contributions, offsets up to 800k elements (3 passes), heavy and light duplication, and a destination
+    # walked backwards (negative row stride: keys are offsets relative to the smallest reachable one)
+    for R, hi in ((100_000, 100_000), (100_000, 37), (257, 257)):
+        base = (rng.standard_normal((R, 8)) * 3).astype(np.float32)
+        idx = rng.integers(0, hi, (300_000,))
+        vals = (rng.standard_normal((300_000, 8)) * 3).astype(np.float32)
+        exp = base.copy()
+        np.add.at(exp, idx, vals)
+        d = nd.asarray(base)
+        nd.index_add(d, nd.asarray(idx), nd.asarray(vals))
+        assert np.array_equal(np.asarray(d), exp), (R, hi)
+        exp = base.copy()
+        np.add.at(exp[::-1], idx, vals)
+        d = nd.asarray(base)
+        nd.index_add(d[::-1], nd.asarray(idx), nd.asarray(vals))
+        assert np.array_equal(np.asarray(d), exp), (R, hi, "reversed")
+        exp = base.copy()
+        exp[idx] = vals
+        d = nd.asarray(base)
+        d[nd.asarray(idx)] = nd.asarray(vals)
+        assert np.array_equal(np.asarray(d), exp), (R, hi, "set")
     d = nd.asarray(np.zeros((50, 64), dtype=np.float32))
     with pytest.raises(IndexError):
         nd.index_add(d, nd.asarray(np.array([0, 50] * 100)), nd.asarray(np.ones((200, 64), dtype=np.float32)))
