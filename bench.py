@@ -372,6 +372,9 @@ def main():
 
     def make_comm(workload):
         comm, kind = None, "none"
+        if use_dist and workload in ("cfg2", "cfg4") and os.environ.get("MDHIP_BENCH_HOST_COMM") == "1":
+            # tests only (tests/test_bench_contract.py): the N > 1 control flow over gloo on the CPU test double
+            return dp.HostComm(rank, world, dist, torch), "gloo-host(test)"
         if use_dist and workload in ("cfg2", "cfg4"):
             if args.comm == "rccl":
                 err = None
@@ -408,6 +411,8 @@ def main():
             kw = {"rank": rank, "world": world}
             if size:
                 kw["batch"] = size
+            if os.environ.get("MDHIP_BENCH_CFG4_DIM"):   # tests only: a layer the CPU double's plain-loop GEMM can afford
+                kw["d_in"] = kw["d_out"] = int(os.environ["MDHIP_BENCH_CFG4_DIM"])
         elif size:
             kw = {"n": size}
         if keep is not None and "state" in keep:
@@ -547,7 +552,7 @@ def main():
 
     # ---- the other BASELINE configs, same process, after the headline's timed region -------------------
     secondary = None
-    if not args.no_secondary and not args.size and not args.graph:
+    if not args.no_secondary and not args.graph and (not args.size or os.environ.get("MDHIP_BENCH_HOST_COMM") == "1"):
         secondary = {}
         gc.collect()
         lib.empty_cache()
@@ -565,7 +570,7 @@ def main():
                 gc.collect()
                 lib.empty_cache()
             try:
-                r = run(wl, lz, k_sec, w_sec, keep=keep)
+                r = run(wl, lz, k_sec, w_sec, size=args.size, keep=keep)
                 r.pop("kernels" if wl in ("cfg2", "cfg5") else "_none", None)
                 secondary[name] = r
             except Exception as e:  # a secondary config must never take the headline down

@@ -131,7 +131,19 @@ class HostComm:
     def __init__(self, rank: int, world: int, dist, torch):
         self.rank, self.world, self.dist, self.torch = rank, world, dist, torch
 
-    def allreduce_sum_(self, arr: np.ndarray):
+    def allreduce_sum_(self, arr):
+        if not isinstance(arr, np.ndarray):
+            # a DeviceArray of the CPU test double (its "device" memory is host memory): reduce it in place through a NumPy view
+            from . import _capi
+
+            lib = _capi.current()
+            if lib is None or lib.target == _capi.PRODUCT_TARGET:
+                raise TypeError("HostComm reduces host memory only (tests); use RcclComm for device arrays")
+            if not arr.is_c_contiguous:
+                raise ValueError("allreduce needs a contiguous buffer")
+            lib.sync()
+            raw = (C.c_char * arr.nbytes).from_address(arr.ptr)
+            arr = np.frombuffer(raw, dtype=arr.dtype)
         t = self.torch.from_numpy(arr)
         self.dist.all_reduce(t)
 
