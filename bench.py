@@ -480,6 +480,17 @@ def main():
         kernel_ms = timer.collect()
         ms_per_step = elapsed / steps * 1e3
         timer.only = None
+        # SURVEY 8d also asks for the median and the minimum of single sweeps: ten more sweeps, each synchronised at its
+        # end (outside the timed region: a per-sweep sync costs the overlap between consecutive sweeps)
+        single = []
+        if not graph:
+            for _ in range(10):
+                barrier()
+                t1 = time.perf_counter()
+                sweep()
+                lib.sync()
+                single.append((time.perf_counter() - t1) * 1e3)
+            single.sort()
         if not graph and workload in ("cfg3", "cfg4"):   # detail pass: every kernel of the sweep bracketed, outside the timed region
             timer.enabled = True
             for _ in range(min(steps, 5)):
@@ -527,6 +538,7 @@ def main():
         res = {
             "value": value, "unit": "passes/s", "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup, "preroll_sweeps": preroll,
             "scaling": scaling,
+            "single_sweep_ms": {"median": single[len(single) // 2], "min": single[0], "n": len(single)} if single else None,
             "config": {"workload": describe(workload, n, lazy), "parallelism": f"dp{world}", "lazy_fusion": bool(lazy),
                        "graph_replay": bool(graph), "collective": comm_kind, "allreduce_bytes": sync.nbytes if use_dist else 0,
                        "allreduce_overlapped_sweeps": sync.overlapped, "allreduce_panels": getattr(sync, "panels", 1),
@@ -590,6 +602,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": head["config"],
             "roofline": head["roofline"], "cpu_baseline": cpu,
+            "single_sweep_ms": head["single_sweep_ms"],
         }
         if "tensors_per_s" in head:
             line["tensors_per_s"] = head["tensors_per_s"]
