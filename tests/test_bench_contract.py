@@ -60,6 +60,6 @@ def test_bench_two_ranks_control_flow_over_gloo(lib, on_gpu):
     assert d["config"]["workload"].startswith("cfg4") and d["tensors_per_s"] == pytest.approx(64 * d["value"])
     assert d["config"]["allreduce_panels"] == 2 and d["config"]["allreduce_bytes"] == (512 * 512 + 512) * 4
     # every sweep (pre-roll + warm-up + timed + the per-kernel detail pass) sent its collectives from inside backward()
-    assert d["config"]["allreduce_overlapped_sweeps"] == d["preroll_sweeps"] + 1 + 2 + 2
+    assert d["config"]["allreduce_overlapped_sweeps"] == d["preroll_sweeps"] + 1 + 2 + 10 + 2   # (+ ten single synchronised sweeps)
     sec = d["secondary"]["cfg2_weak"]
     assert "error" not in sec and sec["scaling"] == "weak" and sec["config"]["collective"] == "gloo-host(test)" and sec["value"] > 0

@@ -115,4 +115,4 @@ def test_bench_distributed_path_on_one_gpu(on_gpu, comm, workload):
     assert line["config"]["collective"] == ("rccl-direct" if comm == "rccl" else "rccl-torch"), line["config"]
     assert line["config"]["allreduce_bytes"] > 0 and line["value"] > 0
     # every sweep's collective (pre-roll + warm-up + timed, + the detail pass of cfg4) left from inside backward()
-    assert line["config"]["allreduce_overlapped_sweeps"] == line["preroll_sweeps"] + 1 + 3 + (3 if workload == "cfg4" else 0)
+    assert line["config"]["allreduce_overlapped_sweeps"] == line["preroll_sweeps"] + 1 + 3 + 10 + (3 if workload == "cfg4" else 0)
