@@ -29,6 +29,9 @@
 // (k_gemm_f64_mfma). Integers / tiny problems: a plain LDS-tiled kernel.
 #include <stdlib.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "md_hip.h"
 
 extern "C" int mdhip_alloc(size_t, void **);
@@ -57,6 +60,8 @@ struct GemmArgs {
   const float *bias;
   uint8_t *mask;
   float *partial;
+  // diagnostic (MDHIP_GEMM_STAMP=1, never set in production): per block {shader cycles, 100 MHz ticks} around the whole kernel body
+  unsigned long long *stamp;
 };
 
 // Tile loaders for a ROWS x BK operand tile, NT threads, 16 B per thread per pass.
@@ -161,6 +166,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (EPI != 0 && BM * BN <= 256 * 12
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l32 = lane & 31, h = lane >> 5;
+  unsigned long long st_c = 0, st_r = 0;
+  if (g.stamp) { st_c = __builtin_amdgcn_s_memtime(); st_r = __builtin_amdgcn_s_memrealtime(); }
 
   f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -261,6 +268,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (EPI != 0 && BM * BN <= 256 * 12
     }
   }
 
+  if (g.stamp && threadIdx.x == 0) {   // (the stamps go to a buffer of their own: MI355X_MICROARCH.md "DVFS give-back" item 6)
+    g.stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c;
+    g.stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r;
+  }
   if constexpr (EPI == 1) {
     // fused epilogue of  loss = sum(where(X @ W + b > 0, X @ W + b, 0))  (reference call pattern: matmul
     // definitions.py:487-492 -> add :424-427 -> greater :468-471 -> where :555-559 -> sum :403-407): the pre-activation
@@ -381,6 +392,33 @@ __global__ void __launch_bounds__(MD_BLOCK) k_gemm_splitk_sum(const float *__res
   }
 }
 
+// diagnostic only (MDHIP_GEMM_STAMP=1): one persistent stamp buffer; what the last stamped launch wrote is printed at exit
+struct StampDump {
+  static constexpr size_t kMax = 8192;
+  unsigned long long *dev = nullptr;
+  int bm = 0, bn = 0, bk = 0;
+  size_t blocks = 0;
+  static StampDump &get() { static StampDump d; return d; }
+  unsigned long long *buffer() {
+    if (!dev) (void)hipMalloc((void **)&dev, kMax * 16);
+    return dev;
+  }
+  void note(int m, int n, int k, size_t b) { bm = m; bn = n; bk = k; blocks = b; }
+  ~StampDump() {
+    if (!dev || !blocks) return;
+    std::vector<unsigned long long> h(blocks * 2);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    std::vector<double> ghz, us;
+    for (size_t b = 0; b < blocks; ++b)
+      if (h[2 * b + 1]) { ghz.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 0.1); us.push_back((double)h[2 * b + 1] * 0.01); }
+    std::sort(ghz.begin(), ghz.end());
+    std::sort(us.begin(), us.end());
+    if (!ghz.empty())
+      fprintf(stderr, "[mdhip] last gemm %dx%dx%d: in-kernel clock median %.3f GHz (min %.3f, max %.3f) over %zu blocks; block main loop median %.1f us (min %.1f, max %.1f)\n",
+              bm, bn, bk, ghz[ghz.size() / 2], ghz.front(), ghz.back(), ghz.size(), us[us.size() / 2], us.front(), us.back());
+  }
+};
+
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int SCHED = 0, int EPI = 0>
 static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
   ga.tiles_m = (int)((ga.M + BM - 1) / BM);
@@ -426,6 +464,11 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
       if (edge) k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, true, true><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
       else k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, false, true><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
     }
+  }
+  static const bool stamp = [] { const char *e = getenv("MDHIP_GEMM_STAMP"); return e && atoi(e) == 1; }();
+  if (stamp && splits == 1 && !edge && (size_t)grid.x * grid.z <= StampDump::kMax) {
+    ga.stamp = StampDump::get().buffer();   // persistent: no sync behind the launch, the LAST launch's stamps are printed at exit
+    StampDump::get().note(BM, BN, BK, (size_t)grid.x * grid.z);
   }
   if (splits == 1) {
     if (edge) k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, true><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
@@ -696,7 +739,7 @@ struct HipExec {
       const bool b_kc = g.b_ks == 1 || g.K == 1, b_nc = g.b_ns == 1 || g.N == 1;
       const bool big = g.M * g.N >= 64 * 64 && g.K >= 8;
       if (big && (a_kc || a_mc) && (b_kc || b_nc) && g.M * g.N < (1ll << 40)) {
-        GemmArgs ga;
+        GemmArgs ga{};  // (zero: no epilogue outputs, no diagnostic stamps)
         ga.A = (const float *)g.a; ga.B = (const float *)g.b; ga.C = (float *)g.c;
         ga.M = g.M; ga.N = g.N; ga.K = g.K;
         ga.a_bs = g.a_bs; ga.a_ms = g.a_ms; ga.a_ks = g.a_ks;
