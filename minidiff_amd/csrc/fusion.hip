@@ -587,7 +587,7 @@ static int reduce_typed(const mdhip_vm_program *pr, int rop, const mdhip_array *
     int grid;
     if (fn) {
       jit::fill_args(&A, pr, D);
-      grid = jit::stream_grid(&A, rows, inner);
+      grid = jit::stream_grid(&A, rows, inner, 4);   // read-only streams: 4 blocks per CU (cfg3 loss pass 137-143 -> 126 us)
     } else {
       grid = md_grid_for((rows * (inner >> 2) + VG - 1) / VG + (rows == 1 ? 4 : 0));
     }
