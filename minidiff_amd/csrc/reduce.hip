@@ -590,8 +590,9 @@ struct HipExec {
       return rc;
     }
     if (rows_ok) {
-      // ~2048 blocks in total; each block should still see >= 4096 items
-      int64_t splits = 2048 / n_out;
+      // ~1024 blocks in total (4 per CU; MDHIP_ROWS_BLOCKS overrides: experiments); each block should still see >= 4096 items
+      static const int64_t total_blocks = [] { const char *e = getenv("MDHIP_ROWS_BLOCKS"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 1024); }();
+      int64_t splits = total_blocks / n_out;
       const int64_t max_splits = ceil_div(n_red, 4096);
       if (splits > max_splits) splits = max_splits;
       if (splits < 1) splits = 1;
