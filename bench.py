@@ -184,10 +184,10 @@ DEFAULT_SIZE = {"cfg2": 4096, "cfg3": 100_000_000, "cfg4": 8192, "cfg5": 2048}
 def describe(workload, n, lazy):
     mode = " [lazy fusion]" if lazy else ""
     return {
-        "cfg2": f"cfg2: C=A@B ({n}x{n} fp32), C.backward(); 3 GEMMs NN/NT/TN; per-rank batch block, B.grad all-reduced",
+        "cfg2": f"cfg2: C=A@B ({n}x{n} fp32), C.backward(); 3 GEMMs NN/NT/TN; per-rank batch block, B.grad all-reduced" + mode,
         "cfg3": f"cfg3: sum((sin(x)*y)**2).backward(), N={n} fp32" + (mode if lazy else " [eager: 11 kernels]"),
         "cfg4": f"cfg4: sum(relu(X@W+b)).backward(), global batch {n} x 4096 -> 4096, row-sharded" + mode,
-        "cfg5": f"cfg5: second order on {n}x{n} matmul, 5 GEMMs",
+        "cfg5": f"cfg5: second order on {n}x{n} matmul, 5 GEMMs" + (" [lazy: products whose result nothing reads (the first-order B.grad) are never launched — NOT the 5-GEMM workload]" if lazy else ""),
     }[workload]
 
 

@@ -12,12 +12,14 @@ from __future__ import annotations
 import numpy as np
 
 
-def _finish(md, *tensors):
-    """A sweep is complete when its gradients are IN MEMORY: in lazy mode this is
-    what triggers the fused kernels (a no-op for eager engines)."""
+def _finish(md, *tensors, outputs=()):
+    """A sweep is complete when its gradients AND its forward output are IN MEMORY: in lazy mode this
+    is what triggers the fused kernels and the deferred products (a no-op for eager engines). Without
+    the output a lazily evaluated `C = A @ B; C.backward()` would never launch the forward product
+    (nothing reads C) and the sweep would not be the workload it claims to be."""
     mat = getattr(md.backend, "_materialize_many", None)
     if mat is not None:
-        mat([t.grad._data for t in tensors if t is not None and t.grad is not None])
+        mat([t.grad._data for t in tensors if t is not None and t.grad is not None] + [o._data for o in outputs])
 
 
 def _randn(seed, shape, scale=1.0):
@@ -38,7 +40,7 @@ def make_cfg2(md, n=4096, seed=2, rank=0):
         B.grad = None
         C = A @ B
         C.backward()
-        _finish(md, A, B)
+        _finish(md, A, B, outputs=(C,))
         return {"A": A, "B": B, "out": C}
 
     return {"A": A, "B": B, "params": [B], "flops": 3 * 2 * n ** 3, "rows": n}, step
@@ -54,7 +56,7 @@ def make_cfg3(md, n=100_000_000, seed=3):
         y.grad = None
         loss = md.sum((md.sin(x) * y) ** 2)
         loss.backward()
-        _finish(md, x, y)
+        _finish(md, x, y, outputs=(loss,))
         return {"x": x, "y": y, "out": loss}
 
     return {"x": x, "y": y, "params": [x, y], "bytes": 100 * n, "rows": n}, step
@@ -81,7 +83,7 @@ def make_cfg4(md, batch=8192, d_in=4096, d_out=4096, seed=4, rank=0, world=1):
         z = X @ W + b
         loss = md.sum(md.where(z > 0, z, 0))
         loss.backward()
-        _finish(md, W, b)
+        _finish(md, W, b, outputs=(loss,))
         return {"W": W, "b": b, "out": loss}
 
     return {"X": X, "W": W, "b": b, "params": [W, b], "flops": 2 * 2 * rows * d_in * d_out, "rows": rows}, step
@@ -98,7 +100,7 @@ def make_cfg5(md, n=2048, seed=5):
         C = A @ B
         C.backward(allow_higher_order=True)
         A.grad.backward()
-        _finish(md, A, B)
+        _finish(md, A, B, outputs=(C,))
         return {"A": A, "B": B, "out": C}
 
     return {"A": A, "B": B, "params": [A, B], "flops": 5 * 2 * n ** 3, "rows": n}, step
