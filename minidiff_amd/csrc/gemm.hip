@@ -99,6 +99,16 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t r
     }
   }
 }
+// one pass (16 B per thread) of load_tile (whole aligned tiles only): lets the k-tile body place the global loads one by one
+template <int ROWS, int BK, int NT, bool KC>
+__device__ __forceinline__ void load_tile_pass(const float *__restrict__ P, int64_t rs, int64_t ks, int64_t row0, int64_t k0, f32x4 (&r)[ROWS * BK / (4 * NT)], int i) {
+  constexpr int TPR = BK / 4, RPP = NT / TPR, TPK = ROWS / 4, KPP = NT / TPK;
+  const int t = threadIdx.x;
+  int row, k;
+  if constexpr (KC) { row = t / TPR + RPP * i; k = (t % TPR) * 4; }
+  else { k = t / TPK + KPP * i; row = (t % TPK) * 4; }
+  r[i] = *reinterpret_cast<const f32x4 *>(P + (row0 + row) * rs + (k0 + k) * ks);
+}
 template <int ROWS, int BK, int NT, bool KC>
 __device__ __forceinline__ void store_tile(float (*S)[ROWS + LDP], const f32x4 (&r)[ROWS * BK / (4 * NT)]) {
   constexpr int PASSES = ROWS * BK / (4 * NT);
@@ -240,7 +250,19 @@ __global__ void __launch_bounds__(64 * WM * WN, (EPI != 0 && BM * BN <= 256 * 12
         // ONE scheduling region, and every MFMA is followed by a slice of the step's memory work
         if (kk == 0) store_tile<BM, BK, NT, A_KC>(As[cur ^ 1], ra);
         if (kk == 2) store_tile<BN, BK, NT, B_KC>(Bs[cur ^ 1], rb);
-        if (kk == 4) {
+        // small tiles (2-4 MFMAs per step): the refill of the staging registers starts the step after they were written to LDS,
+        // one 16-B load per step — A's passes from step 1, then B's — instead of all of them in step 4: a load issued in step 4
+        // has 4 steps x 2 MFMAs (~1000 cycles at two waves per SIMD) to land before its LDS store, which the memory latency
+        // exceeds (ablation: the operand loads cost these tiles 11 %, the 256x128 tile 4 %); 2048^3: 112.3-113.1 -> 115.7-116.2
+        // TFLOP/s. The 256x128 tile keeps the step-4 burst (spread: 139.6-140.2 -> 137.4-137.9).
+        constexpr bool SPREAD = !EDGE && BM * BN <= 128 * 128;
+        constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT);
+        if constexpr (SPREAD) {
+          const int64_t ktl = more2 ? kt + 2 : nk - 1;
+          const int sidx = kk >> 1;
+          if (sidx >= 1 && sidx - 1 < PA) load_tile_pass<BM, BK, NT, A_KC>(A, g.a_ms, g.a_ks, m0, ktl * BK, ra, sidx - 1);
+          if (sidx - 1 >= PA && sidx >= 2 && sidx - 1 - PA < PB) load_tile_pass<BN, BK, NT, B_KC>(B, g.b_ns, g.b_ks, n0, ktl * BK, rb, sidx - 1 - PA);
+        } else if (kk == 4) {
           const int64_t ktl = more2 ? kt + 2 : nk - 1;
           load_tile<BM, BK, NT, A_KC, EDGE>(A, g.a_ms, g.a_ks, m0, ktl * BK, g.M, Kl, ra, vec_ok);
           load_tile<BN, BK, NT, B_KC, EDGE>(B, g.b_ns, g.b_ks, n0, ktl * BK, g.N, Kl, rb, vec_ok);
@@ -254,7 +276,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (EPI != 0 && BM * BN <= 256 * 12
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // one LDS read (next step's fragments)
           if (kk == 0 || kk == 2) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);  // LDS writes of the staged tile
-          if (kk == 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // one global load of tile kt+2
+          if (SPREAD ? (m == 0 && kk >= 2) : kk == 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // one global load of tile kt+2
         }
       }
     }
