@@ -10,7 +10,7 @@
 // f32: v_mfma_f32_32x32x2_f32 — exact f32 fma chain in k order, 256 FLOP/clk/CU
 // (MI355X_MICROARCH.md "Matrix cores"): bound = 157.3 TFLOP/s.
 //   block tile BM x BN x BK (256x128x16 for large problems; a cost model picks smaller tiles
-//   for grids that do not fill whole rounds), 4 waves (2x2), each wave (BM/2)x(BN/2) in 32x32
+//   for grids that do not fill whole rounds), 4 waves (2x2; 8 on the 128x128 tile of one-tile-per-CU grids), each wave (BM/2)x(BN/2) in 32x32
 //   MFMA tiles (128 accumulator VGPRs at 256x128). Operands are staged in LDS k-major ([k][m], [k][n])
 //   so a fragment read is one conflict-free ds_read_b32 per MFMA operand. Three
 //   tiles are in flight per block: LDS buffer `cur` (being multiplied), the other
@@ -135,7 +135,7 @@ __device__ __forceinline__ void store_tile(float (*S)[ROWS + LDP], const f32x4 (
 // variants DECLARE it: left alone the bias/relu epilogue took 171 + 128 registers, one wave per SIMD, the whole product 5 % slower.
 // The plain kernel keeps its allocation — 61 VGPRs + 128 AGPRs — untouched.)
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool EDGE, bool SPLITK = false, int SCHED = 0, int EPI = 0>
-__global__ void __launch_bounds__(64 * WM * WN, (EPI != 0 && BM * BN <= 256 * 128) ? 2 : 1) k_gemm_f32_mfma(GemmArgs g) {
+__global__ void __launch_bounds__(64 * WM * WN, (EPI != 0 && BM * BN <= 256 * 128 && WM * WN <= 4) ? 2 : 1) k_gemm_f32_mfma(GemmArgs g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);  // MFMA tiles per wave along m / n
   __shared__ float As[2][BK][BM + LDP];
@@ -506,8 +506,8 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
   return MD_LAUNCH_CHECK("matmul(f32 mfma)");
 }
 
-// (128x128x32, 8-wave 256x128 and 256x256 tiles were measured and dropped: profiles/r1_gemm_tile_ab.log)
-enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_256x256x32, CFG_128x128x32, CFG_128x64x32, CFG_COUNT };
+// (128x128x32, 8-wave 256x128 and 256x256 tiles were measured and dropped: profiles/r1_gemm_tile_ab.log, r2_gemm_small_grid_ab.log)
+enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_256x256x32, CFG_128x128x32, CFG_128x64x32, CFG_128x128_W8, CFG_COUNT };
 
 static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged) {
   if (const char *e = getenv("MDHIP_GEMM_CFG")) {  // experiments only
@@ -520,7 +520,7 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged) {
   // (4097 rows: 3 rounds of 256x128 against 17 of 64x64, i.e. 0.80x the time).
   if (((ga.M + 63) / 64) * ((ga.N + 63) / 64) * batch < MD_NUM_CUS && ga.K >= 1024) return CFG_64x64x16;  // split-K candidates
   struct Cand { int cfg, bm, bn; double tf; };
-  static const Cand cands[] = {{CFG_256x128x16, 256, 128, 139.0}, {CFG_128x128x16, 128, 128, 133.0},
+  static const Cand cands[] = {{CFG_256x128x16, 256, 128, 139.0}, {CFG_128x128x16, 128, 128, 133.0}, {CFG_128x128_W8, 128, 128, 133.0},
                                {CFG_128x64x16, 128, 64, 126.0}, {CFG_64x64x16, 64, 64, 120.0}};
   int best = CFG_64x64x16;
   double best_t = 1e300;
@@ -531,14 +531,14 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged) {
       best = CFG_256x256x32;
     }
   }
-  static const Cand cands_tn[] = {{CFG_256x128x16, 256, 128, 138.0}, {CFG_128x128x32, 128, 128, 132.0},
+  static const Cand cands_tn[] = {{CFG_256x128x16, 256, 128, 138.0}, {CFG_128x128x32, 128, 128, 132.0}, {CFG_128x128_W8, 128, 128, 134.0},
                                   {CFG_128x64x32, 128, 64, 126.7}, {CFG_64x64x16, 64, 64, 120.0}};
-  for (int ci = 0; ci < 4; ++ci) {
+  for (int ci = 0; ci < 5; ++ci) {
     const Cand &c = vector_staged ? cands_tn[ci] : cands[ci];
     const int64_t tiles = ((ga.M + c.bm - 1) / c.bm) * ((ga.N + c.bn - 1) / c.bn) * batch;
     const double rounds = (double)((tiles + MD_NUM_CUS - 1) / MD_NUM_CUS);
     double t = rounds * c.bm * c.bn / c.tf;
-    if (tiles <= MD_NUM_CUS) t /= 0.8;  // a lone block per CU (one wave per SIMD) cannot keep the matrix pipe fed
+    if (tiles <= MD_NUM_CUS && c.cfg != CFG_128x128_W8) t /= 0.8;  // a lone four-wave block per CU (one wave per SIMD) cannot keep the matrix pipe fed
     if (t < best_t * 0.999) { best_t = t; best = c.cfg; }   // ties go to the larger tile (listed first)
   }
   return best;
@@ -562,6 +562,13 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
     case CFG_256x256x32:  // both operands staged with vector LDS stores (TN): one block per CU, half the barriers
       if constexpr (!A_KC && !B_KC) return launch_cfg<256, 256, 32, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
       else return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
+    // eight waves on ONE 128x128 tile: two waves per SIMD from a single block per CU — for grids of about one tile per CU
+    // (2048^3, the 1024-row shards of cfg4 at 8 ranks), where the four-wave tiles either leave every SIMD one wave
+    // (128x128) or pay for twice the operand traffic (two 128x64 blocks): 2048^3 109-114 -> 118-123 TFLOP/s,
+    // 1024x4096x4096 114-118 -> 122-126 (profiles/r2_gemm_small_grid_ab.log)
+    case CFG_128x128_W8:
+      if constexpr (!A_KC && !B_KC) return launch_cfg<128, 128, 32, 4, 2, A_KC, B_KC, 1>(ga, batch, edge);
+      else return launch_cfg<128, 128, 16, 2, 4, A_KC, B_KC, 1>(ga, batch, edge);
     default: return launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
   }
 }
@@ -830,13 +837,13 @@ __global__ void __launch_bounds__(MD_BLOCK) k_gemm_epi_finish(const float *__res
   if (threadIdx.x == 0) out[0] = sm[0];
 }
 
-template <int BM, int BN> static int launch_epi(GemmArgs ga) {
+template <int BM, int BN, int WM = 2, int WN = 2> static int launch_epi(GemmArgs ga) {
   const int64_t tiles = ((ga.M + BM - 1) / BM) * ((ga.N + BN - 1) / BN);
   void *partial = nullptr;
   MD_TRY(mdhip_alloc((size_t)tiles * sizeof(float), &partial));
   float *out = ga.partial;  // (the caller parked the 0-d result pointer here)
   ga.partial = (float *)partial;
-  int rc = launch_cfg<BM, BN, 16, 2, 2, true, false, BM == 64 ? 0 : 1, 1>(ga, 1, false);
+  int rc = launch_cfg<BM, BN, 16, WM, WN, true, false, BM == 64 ? 0 : 1, 1>(ga, 1, false);
   if (rc == MDHIP_OK) {
     k_gemm_epi_finish<<<1, MD_BLOCK, 0, md_stream()>>>((const float *)partial, tiles, out);
     rc = MD_LAUNCH_CHECK("matmul(bias+relu epilogue, finish)");
@@ -878,6 +885,7 @@ extern "C" int mdhip_matmul_bias_relu_sum(const mdhip_array *a, const mdhip_arra
   // the plain kernel's tile choice, restricted to the tiles that divide the problem
   const int cfg = pick_cfg(ga, 1, false);
   if ((cfg == CFG_256x128x16 || cfg == CFG_256x256x32) && M % 256 == 0 && N % 128 == 0) return launch_epi<256, 128>(ga);
+  if (cfg == CFG_128x128_W8 && M % 128 == 0 && N % 128 == 0) return launch_epi<128, 128, 2, 4>(ga);
   if (M % 128 == 0 && N % 128 == 0 && (cfg == CFG_128x128x16 || cfg == CFG_128x128x32 || cfg == CFG_256x128x16)) return launch_epi<128, 128>(ga);
   if (M % 128 == 0 && N % 64 == 0 && cfg != CFG_64x64x16) return launch_epi<128, 64>(ga);
   if (M % 64 == 0 && N % 64 == 0) return launch_epi<64, 64>(ga);

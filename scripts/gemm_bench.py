@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from minidiff_amd import _capi, ndarray as nd  # noqa: E402
 
-CFGS = {0: "128x128x16", 1: "64x64x16", 2: "128x64x16", 3: "256x128x16", 4: "256x256x32 (TN)", 5: "128x128x32 (TN)", 6: "128x64x32 (TN)"}
+CFGS = {0: "128x128x16", 1: "64x64x16", 2: "128x64x16", 3: "256x128x16", 4: "256x256x32 (TN)", 5: "128x128x32 (TN)", 6: "128x64x32 (TN)", 7: "128x128 8 waves"}
 if os.environ.get("GEMM_CFGS"):
     CFGS = {int(k): CFGS[int(k)] for k in os.environ["GEMM_CFGS"].split(",")}
 

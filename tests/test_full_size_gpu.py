@@ -198,3 +198,40 @@ def test_weight_gradient_in_row_panels_is_bit_identical(engines, on_gpu):
                 sync.close()
     finally:
         comm.close()
+
+
+@pytest.mark.parametrize("tile", range(8))
+def test_every_gemm_tile_config_exact_on_integers(lib, on_gpu, tile, monkeypatch):
+    """Every tile of the f32 MFMA kernel (gemm.hip's CFG_* list, forced through MDHIP_GEMM_CFG, which the library reads
+    at every launch), in the three layouts of definitions.py:487-492, whole and ragged shapes, plain and bias+relu
+    epilogue kernels: small-integer operands make the f32 fma chain exact, so the results must EQUAL NumPy's."""
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    monkeypatch.setenv("MDHIP_GEMM_CFG", str(tile))
+    rng = np.random.default_rng(100 + tile)
+    prev = nd.set_lazy(False)
+    try:
+        for (M, K, N) in ((512, 128, 256), (300, 70, 200), (256, 2048, 128)):
+            A = rng.integers(-4, 5, (M, K)).astype(np.float32)
+            B = rng.integers(-4, 5, (K, N)).astype(np.float32)
+            ref = A.astype(np.float64) @ B
+            dA, dB = nd.asarray(A), nd.asarray(B)
+            dAt, dBt = nd.asarray(np.ascontiguousarray(A.T)), nd.asarray(np.ascontiguousarray(B.T))
+            for tag, a, b in (("NN", dA, dB), ("NT", dA, dBt.T), ("TN", dAt.T, dB), ("TT", dAt.T, dBt.T)):
+                assert np.array_equal(nd.matmul(a, b).get(), ref), (tile, tag, M, K, N)
+        # epilogue kernel of the same tile (lazy mode recognises sum(where(X@W+b > 0, X@W+b, 0)))
+        nd.set_lazy(True)
+        M, K, N = 512, 64, 256
+        X = rng.integers(-3, 4, (M, K)).astype(np.float32)
+        W = rng.integers(-3, 4, (K, N)).astype(np.float32)
+        b = (rng.integers(-3, 4, N) + 0.5).astype(np.float32)     # (never exactly 0 after the add)
+        s0 = nd.FUSION_STATS["gemm_epilogue"]
+        z = nd.add(nd.matmul(nd.asarray(X), nd.asarray(W)), nd.asarray(b))
+        m = nd.greater(z, 0)
+        loss = nd.sum(nd.where(m, z, 0))
+        zr = X.astype(np.float64) @ W + b
+        assert nd.FUSION_STATS["gemm_epilogue"] - s0 == 1, tile
+        assert np.array_equal(m.get(), zr > 0), tile
+        assert abs(float(loss.get()) - np.where(zr > 0, zr, 0).sum()) <= 1e-6 * np.abs(zr).sum(), tile
+    finally:
+        nd.set_lazy(prev)
