@@ -375,6 +375,139 @@ __global__ void __launch_bounds__(64 * WM * WN, (EPI != 0 && BM * BN <= 256 * 12
     }
 }
 
+// ---- TN products (both operands row-contiguous along the tile's rows) staged global -> LDS directly ------------------
+// global_load_lds_dwordx4: one wave-instruction moves 64 lanes x 16 B = 1 KiB of the unpadded [BK][ROWS] image (ROWS/256 of a
+// k-row, or 256/ROWS whole k-rows): no staging registers, no ds_write. The LDS address is wave-uniform (M0) + lane * 16, the
+// SOURCE address is per lane. One tile ahead: tile kt+1 lands in the other buffer while tile kt is multiplied, and the barrier
+// that ends the k-tile waits for it (vmcnt(0), which __syncthreads() emits for an LDS-DMA in flight). The two buffers of an
+// operand are SEPARATE __shared__ objects and the k-loop is unrolled by two with the buffer fixed at compile time: with one
+// array indexed by a runtime `cur` the compiler cannot tell the fragment reads of buffer cur from the DMA writes to cur^1 and
+// drains the DMA (s_waitcnt vmcnt(0)) in front of every step's ds_read (seen in the .s of the first version of this kernel).
+typedef __attribute__((address_space(3))) void md_lds_void;
+typedef __attribute__((address_space(1))) const void md_gbl_void;
+template <int ROWS, int BK, int NT>
+__device__ __forceinline__ void glds_tile_pass(const float *__restrict__ P, int64_t ks, int64_t row0, int64_t k0, float *S, int i) {
+  constexpr int NW = NT / 64;
+  static_assert(ROWS * BK % (256 * NW) == 0 && (ROWS & (ROWS - 1)) == 0, "whole 1-KiB pieces per wave");
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int piece = i * NW + wave;
+  const int f = piece * 256 + lane * 4, k = f / ROWS, r = f % ROWS;
+  __builtin_amdgcn_global_load_lds((md_gbl_void *)(P + (row0 + r) + (k0 + k) * ks), (md_lds_void *)(S + piece * 256), 16, 0, 0);
+}
+
+template <int V> struct MdInt { static constexpr int value = V; };
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);
+  constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NSTEP = BK / 2;
+  constexpr int PPS = (PA + PB + NSTEP / 2 - 1) / (NSTEP / 2);   // DMA pieces per step: all of them inside the first half of the k-tile
+  __shared__ float A0[BK][BM];
+  __shared__ float A1[BK][BM];
+  __shared__ float B0[BK][BN];
+  __shared__ float B1[BK][BN];
+
+  const int nblk = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // XCD-aware tile order, as in k_gemm_f32_mfma
+  int tm, tn;
+  if (g.super_h > 1) {
+    const int band = bid / (g.super_h * g.tiles_n), within = bid - band * (g.super_h * g.tiles_n);
+    const int hgt = (band + 1) * g.super_h <= g.tiles_m ? g.super_h : g.tiles_m - band * g.super_h;
+    tn = within / hgt;
+    tm = band * g.super_h + within - tn * hgt;
+  } else {
+    tm = bid / g.tiles_n;
+    tn = bid - tm * g.tiles_n;
+  }
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t bz = blockIdx.z;
+  const float *A = g.A + bz * g.a_bs;
+  const float *B = g.B + bz * g.b_bs;
+  float *C = g.C + bz * g.c_bs;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l32 = lane & 31, h = lane >> 5;
+  const int am = wm * (WTM * 32) + l32, bn = wn * (WTN * 32) + l32;
+
+  f32x16 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int64_t nk = g.K / BK;   // whole k-tiles only (the launcher checks)
+#pragma unroll
+  for (int i = 0; i < PA; ++i) glds_tile_pass<BM, BK, NT>(A, g.a_ks, m0, 0, &A0[0][0], i);
+#pragma unroll
+  for (int i = 0; i < PB; ++i) glds_tile_pass<BN, BK, NT>(B, g.b_ks, n0, 0, &B0[0][0], i);
+  __syncthreads();
+
+  float fa[2][WTM], fb[2][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) fa[0][i] = A0[h][am + i * 32];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) fb[0][j] = B0[h][bn + j * 32];
+
+  // one k-tile out of buffer CUR; tile `kn` (clamped by the caller: a redundant last prefetch is never read) goes to the other one
+  auto ktile = [&](auto curc, int64_t kn) {
+    constexpr int CUR = decltype(curc)::value;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const int c = (kk >> 1) & 1, sidx = kk >> 1;
+      if (kk + 2 < BK) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) fa[c ^ 1][i] = CUR ? A1[kk + 2 + h][am + i * 32] : A0[kk + 2 + h][am + i * 32];
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) fb[c ^ 1][j] = CUR ? B1[kk + 2 + h][bn + j * 32] : B0[kk + 2 + h][bn + j * 32];
+      }
+      int n_dma = 0;
+#pragma unroll
+      for (int q = 0; q < PPS; ++q) {
+        const int pi = sidx * PPS + q;
+        if (pi < PA) { glds_tile_pass<BM, BK, NT>(A, g.a_ks, m0, kn * BK, CUR ? &A0[0][0] : &A1[0][0], pi); ++n_dma; }
+        else if (pi < PA + PB) { glds_tile_pass<BN, BK, NT>(B, g.b_ks, n0, kn * BK, CUR ? &B0[0][0] : &B1[0][0], pi - PA); ++n_dma; }
+      }
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < WTM * WTN; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // one LDS read (next step's fragments)
+        if (m < n_dma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // one LDS-DMA piece of the next tile
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) fa[0][i] = CUR ? A0[h][am + i * 32] : A1[h][am + i * 32];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) fb[0][j] = CUR ? B0[h][bn + j * 32] : B1[h][bn + j * 32];
+  };
+  int64_t kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    ktile(MdInt<0>{}, kt + 1);
+    ktile(MdInt<1>{}, kt + 2 < nk ? kt + 2 : nk - 1);
+  }
+  if (kt < nk) ktile(MdInt<0>{}, nk - 1);
+
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int64_t col = n0 + wn * (WTN * 32) + j * 32 + l32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * (WTM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        C[row * g.c_ms + col * g.c_ns] = acc[i][j][r];
+      }
+    }
+}
+
 // ---- plain tiled kernel: any dtype, any strides (f64 / ints / tiny problems) ------
 template <class T>
 __global__ void __launch_bounds__(256) k_gemm_generic(MdGemm g) {
@@ -494,7 +627,19 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
   }
   if (splits == 1) {
     if (edge) k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, true><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
-    else k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, false, false, SCHED><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
+    else {
+      bool glds = false;
+      if constexpr (!A_KC && !B_KC && SCHED != 0 && BK >= 32) {
+        // TN with whole aligned tiles and 32-deep k-tiles: both operands go direct to LDS (MDHIP_GEMM_GLDS=0, read at every
+        // launch, keeps the register-staged kernel: A/B runs). Same-box A/B, profiles/r2_gemm_glds_ab.log: 256x256x32 at
+        // 4096^3 140.1 -> 141.9 TFLOP/s, the 8-wave 128x128x32 at 2048^3 119.0 -> 127.8; the 16-deep 256x128 tile LOSES
+        // (135.7 -> 130.8: its k-tile is too short for a one-tile-ahead DMA) and keeps its registers.
+        const char *e = getenv("MDHIP_GEMM_GLDS");
+        glds = (e ? atoi(e) != 0 : true) && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp;
+        if (glds) k_gemm_f32_tn_glds<BM, BN, BK, WM, WN><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
+      }
+      if (!glds) k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, false, false, SCHED><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
+    }
   }
   if (splits > 1) {
     k_gemm_splitk_sum<<<md_grid_for(batch * ga.M * ga.N), MD_BLOCK, 0, md_stream()>>>((const float *)partial, (int)splits, batch, ga.M, ga.N,

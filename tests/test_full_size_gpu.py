@@ -200,18 +200,20 @@ def test_weight_gradient_in_row_panels_is_bit_identical(engines, on_gpu):
         comm.close()
 
 
+@pytest.mark.parametrize("glds", ["1", "0"])
 @pytest.mark.parametrize("tile", range(8))
-def test_every_gemm_tile_config_exact_on_integers(lib, on_gpu, tile, monkeypatch):
+def test_every_gemm_tile_config_exact_on_integers(lib, on_gpu, tile, glds, monkeypatch):
     """Every tile of the f32 MFMA kernel (gemm.hip's CFG_* list, forced through MDHIP_GEMM_CFG, which the library reads
     at every launch), in the three layouts of definitions.py:487-492, whole and ragged shapes, plain and bias+relu
     epilogue kernels: small-integer operands make the f32 fma chain exact, so the results must EQUAL NumPy's."""
     assert on_gpu
     from minidiff_amd import ndarray as nd
     monkeypatch.setenv("MDHIP_GEMM_CFG", str(tile))
+    monkeypatch.setenv("MDHIP_GEMM_GLDS", glds)     # TN with 32-deep k-tiles: direct-to-LDS kernel / register-staged kernel
     rng = np.random.default_rng(100 + tile)
     prev = nd.set_lazy(False)
     try:
-        for (M, K, N) in ((512, 128, 256), (300, 70, 200), (256, 2048, 128)):
+        for (M, K, N) in ((512, 128, 256), (300, 70, 200), (256, 2048, 128), (256, 96, 256), (256, 32, 512)):
             A = rng.integers(-4, 5, (M, K)).astype(np.float32)
             B = rng.integers(-4, 5, (K, N)).astype(np.float32)
             ref = A.astype(np.float64) @ B
