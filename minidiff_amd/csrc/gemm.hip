@@ -127,6 +127,85 @@ __device__ __forceinline__ void store_tile(float (*S)[ROWS + LDP], const f32x4 (
   }
 }
 
+// Fused epilogue of  loss = sum(where(X @ W + b > 0, X @ W + b, 0))  (reference call pattern: matmul
+// definitions.py:487-492 -> add :424-427 -> greater :468-471 -> where :555-559 -> sum :403-407): the pre-activation
+// never goes to memory; what the backward pass needs of it — the mask — does, as numpy.bool_ bytes, and the block's
+// relu sum goes to partial[blockIdx.x] (summed in index order by k_gemm_epi_finish).
+// The accumulator layout gives a lane ONE column and 16 rows: written as it stands the mask would go out in 32-byte
+// pieces of single bytes (measured: +106 us on the 8192 x 4096 x 4096 product). Instead the four lanes of a quad
+// exchange their 16 result bits, each lane packs the 4 adjacent columns of 4 of the rows into one dword, the tile's
+// mask is assembled in LDS (`sm`: an operand buffer, free by now; 16-byte groups XOR-swizzled by the row so that
+// neither the dword writes nor the 16-byte reads conflict) and leaves as whole 128-byte rows. NPASS > 1: the tile's
+// rows go through a scratch of BM / NPASS rows in NPASS rounds (256x256 tile: 64 KiB of mask, 32 KiB operand buffers).
+// Called by every thread of the block, behind a barrier that retires the last reads of the operand buffers.
+template <int BM, int BN, int WM, int WN, int NPASS>
+__device__ __forceinline__ void md_epi_bias_relu(const f32x16 (&acc)[BM / (32 * WM)][BN / (32 * WN)], const GemmArgs &g, int64_t m0, int64_t n0,
+                                                 uint32_t *sm, float *red) {
+  constexpr int NT = 64 * WM * WN, WTM = BM / (32 * WM), WTN = BN / (32 * WN);
+  constexpr int FP = WTM / NPASS;              // fragment rows of a wave per pass
+  constexpr int SROWS = BM / NPASS;            // scratch rows
+  static_assert(WTM % NPASS == 0 && BN % 16 == 0, "whole fragment rows per pass, 16-byte mask vectors");
+  constexpr int RW = BN / 4;                   // dwords per mask row of the tile
+  constexpr int GX = (BN / 16) < 8 ? (BN / 16) : 8;   // 16-byte groups per row that take part in the swizzle
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN, l32 = lane & 31, h = lane >> 5;
+  const int q = l32 >> 2, jq = l32 & 3;
+  float lsum = 0.0f;
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    if (p > 0) __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < FP; ++ii) {
+      const int i = p * FP + ii;
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) {
+        const int lcol = wn * (WTN * 32) + j * 32 + l32;
+        const float bv = g.bias[n0 + lcol];
+        uint32_t bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float z = acc[i][j][r] + bv;
+          const bool on = z > 0.0f;
+          lsum += on ? z : 0.0f;
+          bits |= (uint32_t)on << r;
+        }
+        uint32_t qb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) qb[k] = (uint32_t)__shfl((int)bits, (lane & ~3) + k, 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = jq + 4 * t;                                   // this lane packs accumulator rows r = jq, jq+4, jq+8, jq+12
+          const uint32_t d = ((qb[0] >> r) & 1u) | (((qb[1] >> r) & 1u) << 8) | (((qb[2] >> r) & 1u) << 16) | (((qb[3] >> r) & 1u) << 24);
+          const int srow = wm * (FP * 32) + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // scratch row
+          const int w = (wn * (WTN * 32) + j * 32) / 4 + q;          // dword index inside the mask row
+          const int grp = (w >> 2) ^ (srow & (GX - 1));               // swizzled 16-byte group
+          sm[srow * RW + (grp << 2) + (w & 3)] = d;
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int VPR = BN / 16;  // 16-byte vectors per row
+    for (int v = threadIdx.x; v < SROWS * VPR; v += NT) {
+      const int srow = v / VPR, gv = v - srow * VPR;
+      const int swm = srow / (FP * 32), rem = srow - swm * (FP * 32);
+      const int64_t row = m0 + swm * (WTM * 32) + p * (FP * 32) + rem;
+      const uint4 val = *reinterpret_cast<const uint4 *>(sm + srow * RW + ((gv ^ (srow & (GX - 1))) << 2));
+      *reinterpret_cast<uint4 *>(g.mask + row * g.N + n0 + gv * 16) = val;
+    }
+  }
+  // block sum in a fixed order: lanes by shuffle, then the waves through LDS
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) lsum += __shfl_down(lsum, d, 64);
+  if (lane == 0) red[wave] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WM * WN; ++w) t += red[w];
+    g.partial[blockIdx.x] = t;
+  }
+}
+
 // BM x BN block tile, BK k-step, WM x WN waves, each wave (WTM*32) x (WTN*32).
 // SPLITK is a separate instantiation on purpose: with the k-range arithmetic compiled into the plain
 // kernel its main loop came out instruction-for-instruction the same but with another register
@@ -295,70 +374,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (EPI != 0 && BM * BN <= 256 * 12
     g.stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r;
   }
   if constexpr (EPI == 1) {
-    // fused epilogue of  loss = sum(where(X @ W + b > 0, X @ W + b, 0))  (reference call pattern: matmul
-    // definitions.py:487-492 -> add :424-427 -> greater :468-471 -> where :555-559 -> sum :403-407): the pre-activation
-    // never goes to memory; what the backward pass needs of it — the mask — does, as numpy.bool_ bytes.
-    // The accumulator layout gives a lane ONE column and 16 rows: written as it stands the mask would go out in 32-byte
-    // pieces of single bytes (measured: +106 us on the 8192 x 4096 x 4096 product). Instead the four lanes of a quad
-    // exchange their 16 result bits, each lane packs the 4 adjacent columns of 4 of the rows into one dword, the tile's
-    // mask is assembled in LDS (the operand buffers are free now; 16-byte groups XOR-swizzled by the row so that
-    // neither the dword writes nor the 16-byte reads conflict) and leaves as whole 128-byte rows.
     static_assert(sizeof(As) >= (size_t)BM * BN, "the tile's mask must fit the A staging buffers");
-    static_assert(BN % 16 == 0, "16-byte mask vectors");
     __syncthreads();
-    uint32_t *sm = reinterpret_cast<uint32_t *>(&As[0][0][0]);
-    constexpr int RW = BN / 4;   // dwords per mask row of the tile
-    constexpr int GX = (BN / 16) < 8 ? (BN / 16) : 8;   // 16-byte groups per row that take part in the swizzle
-    float lsum = 0.0f;
-    const int q = l32 >> 2, jq = l32 & 3;
-#pragma unroll
-    for (int i = 0; i < WTM; ++i)
-#pragma unroll
-      for (int j = 0; j < WTN; ++j) {
-        const int lcol = wn * (WTN * 32) + j * 32 + l32;
-        const float bv = g.bias[n0 + lcol];
-        uint32_t bits = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float z = acc[i][j][r] + bv;
-          const bool on = z > 0.0f;
-          lsum += on ? z : 0.0f;
-          bits |= (uint32_t)on << r;
-        }
-        uint32_t qb[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) qb[k] = (uint32_t)__shfl((int)bits, (lane & ~3) + k, 64);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int r = jq + 4 * t;                                   // this lane packs accumulator rows r = jq, jq+4, jq+8, jq+12
-          const uint32_t d = ((qb[0] >> r) & 1u) | (((qb[1] >> r) & 1u) << 8) | (((qb[2] >> r) & 1u) << 16) | (((qb[3] >> r) & 1u) << 24);
-          const int lrow = wm * (WTM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int w = (wn * (WTN * 32) + j * 32) / 4 + q;          // dword index inside the mask row
-          const int grp = (w >> 2) ^ (lrow & (GX - 1));               // swizzled 16-byte group
-          sm[lrow * RW + (grp << 2) + (w & 3)] = d;
-        }
-      }
-    __syncthreads();
-    {
-      constexpr int VPR = BN / 16;  // 16-byte vectors per row
-      for (int v = threadIdx.x; v < BM * VPR; v += NT) {
-        const int lrow = v / VPR, gv = v - lrow * VPR;
-        const uint4 val = *reinterpret_cast<const uint4 *>(sm + lrow * RW + ((gv ^ (lrow & (GX - 1))) << 2));
-        *reinterpret_cast<uint4 *>(g.mask + (m0 + lrow) * g.N + n0 + gv * 16) = val;
-      }
-    }
-    // block sum in a fixed order: lanes by shuffle, then the waves through LDS
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) lsum += __shfl_down(lsum, d, 64);
-    float *red = &Bs[0][0][0];
-    if (lane == 0) red[wave] = lsum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float t = 0.0f;
-#pragma unroll
-      for (int w = 0; w < WM * WN; ++w) t += red[w];
-      g.partial[blockIdx.x] = t;
-    }
+    md_epi_bias_relu<BM, BN, WM, WN, 1>(acc, g, m0, n0, reinterpret_cast<uint32_t *>(&As[0][0][0]), &Bs[0][0][0]);
     return;
   }
   // C/D layout of the 32x32 accumulator: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -495,6 +513,167 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
   }
   if (kt < nk) ktile(MdInt<0>{}, nk - 1);
 
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int64_t col = n0 + wn * (WTN * 32) + j * 32 + l32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * (WTM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        C[row * g.c_ms + col * g.c_ns] = acc[i][j][r];
+      }
+    }
+}
+
+// ---- NN / NT products: the k-contiguous operand(s) direct to LDS as well -------------------------------------------------
+// A lane-linear DMA cannot transpose, so the k-contiguous operand keeps its memory order in LDS: 1-KiB pieces of 16 rows x 16 k,
+// stored [k/4][row][4] (lane = (k/4) * 16 + row: the source of one wave-instruction is 16 rows x 64 B, as with register staging).
+// A fragment is then ONE ds_read_b128 per 32 rows and EIGHT k: the lanes of half h take the four k of group 2j+h, and MFMA t of
+// the pair multiplies k = 8j + t (lanes 0-31) and k = 8j + 4 + t (lanes 32-63) — v_mfma_f32_32x32x2 does not care WHICH two k a
+// call carries, only that A and B agree. The sum over k therefore runs in the order (0,4),(1,5),(2,6),(3,7),(8,12).. instead of
+// (0,1),(2,3)..: a different rounding sequence from the register-staged kernel (both are plain f32 fma chains; integers stay exact).
+// B is either k-contiguous too (NT: same image) or row-contiguous (NN: the [k][n] image of k_gemm_f32_tn_glds, b32 reads at
+// k = 8j + 4h + t). 16 consecutive lanes of a b128 read cover one 256-B run of a piece: no bank conflicts.
+template <int ROWS, int BK, int NT>
+__device__ __forceinline__ void glds_kc_pass(const float *__restrict__ P, int64_t rs, int64_t row0, int64_t k0, float *S, int i) {
+  constexpr int NW = NT / 64, KH = BK / 16;
+  static_assert(ROWS * BK % (256 * NW) == 0 && BK % 16 == 0, "whole 1-KiB pieces per wave");
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // a wave takes BOTH k-halves of a 16-row block back to back (the two pieces share their 128-B lines)
+  const int rb = (i / KH) * NW + wave, kh = i % KH;
+  const int row = rb * 16 + (lane & 15), k = kh * 16 + (lane >> 4) * 4;
+  __builtin_amdgcn_global_load_lds((md_gbl_void *)(P + (row0 + row) * rs + k0 + k), (md_lds_void *)(S + (rb * KH + kh) * 256), 16, 0, 0);
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool B_KC, int EPI = 0>
+__global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);
+  constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NSTEP = BK / 2, NP = BK / 8, KH = BK / 16;
+  constexpr int PPS = (PA + PB + NSTEP / 2 - 1) / (NSTEP / 2);
+  static_assert(NP % 2 == 0, "an even number of k-pairs per tile (fragment double buffer)");
+  __shared__ __attribute__((aligned(16))) float A0[BM * BK];
+  __shared__ __attribute__((aligned(16))) float A1[BM * BK];
+  __shared__ __attribute__((aligned(16))) float B0[BN * BK];
+  __shared__ __attribute__((aligned(16))) float B1[BN * BK];
+
+  const int nblk = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  int tm, tn;
+  if (g.super_h > 1) {
+    const int band = bid / (g.super_h * g.tiles_n), within = bid - band * (g.super_h * g.tiles_n);
+    const int hgt = (band + 1) * g.super_h <= g.tiles_m ? g.super_h : g.tiles_m - band * g.super_h;
+    tn = within / hgt;
+    tm = band * g.super_h + within - tn * hgt;
+  } else {
+    tm = bid / g.tiles_n;
+    tn = bid - tm * g.tiles_n;
+  }
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t bz = blockIdx.z;
+  const float *A = g.A + bz * g.a_bs;
+  const float *B = g.B + bz * g.b_bs;
+  float *C = g.C + bz * g.c_bs;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l32 = lane & 31, h = lane >> 5;
+  // lane bases (floats) into the images; fragment i / pair j add compile-time offsets
+  const int arow = wm * (WTM * 32) + l32;
+  const int abase = (arow >> 4) * (KH * 256) + (arow & 15) * 4 + h * 64;
+  const int brow = wn * (WTN * 32) + l32;
+  const int bbase = B_KC ? (brow >> 4) * (KH * 256) + (brow & 15) * 4 + h * 64 : h * 4 * BN + brow;
+
+  f32x16 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int64_t nk = g.K / BK;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) glds_kc_pass<BM, BK, NT>(A, g.a_ms, m0, 0, A0, i);
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    if constexpr (B_KC) glds_kc_pass<BN, BK, NT>(B, g.b_ns, n0, 0, B0, i);
+    else glds_tile_pass<BN, BK, NT>(B, g.b_ks, n0, 0, B0, i);
+  }
+  __syncthreads();
+
+  f32x4 fa[2][WTM], fb[2][WTN];
+  // fragments of k-pair j out of buffer BUF (compile-time) into register set c
+#define MD_KC_READ(BUF, j, c)                                                                                                   \
+  {                                                                                                                             \
+    constexpr int joff = ((j) >> 1) * 256 + (((2 * (j)) & 3) * 64);                                                             \
+    _Pragma("unroll") for (int i = 0; i < WTM; ++i)                                                                             \
+      fa[c][i] = *reinterpret_cast<const f32x4 *>(((BUF) ? A1 : A0) + abase + i * (2 * KH * 256) + joff);                       \
+    _Pragma("unroll") for (int q = 0; q < WTN; ++q) {                                                                           \
+      if constexpr (B_KC) fb[c][q] = *reinterpret_cast<const f32x4 *>(((BUF) ? B1 : B0) + bbase + q * (2 * KH * 256) + joff);   \
+      else {                                                                                                                    \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) fb[c][q][t] = ((BUF) ? B1 : B0)[bbase + (8 * (j) + t) * BN + q * 32];     \
+      }                                                                                                                         \
+    }                                                                                                                           \
+  }
+  MD_KC_READ(0, 0, 0)
+
+  auto ktile = [&](auto curc, int64_t kn) {
+    constexpr int CUR = decltype(curc)::value;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int c = j & 1;
+      if (j + 1 < NP) {
+        // (j + 1 as a constant expression: the loop is fully unrolled, but a macro argument must be usable in constexpr context)
+        if (j == 0) MD_KC_READ(CUR, 1, 1)
+        if (NP > 2 && j == 1) MD_KC_READ(CUR, 2, 0)
+        if (NP > 2 && j == 2) MD_KC_READ(CUR, 3, 1)
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int sidx = j * 4 + t;
+        int n_dma = 0;
+#pragma unroll
+        for (int q = 0; q < PPS; ++q) {
+          const int pi = sidx * PPS + q;
+          if (pi < PA) { glds_kc_pass<BM, BK, NT>(A, g.a_ms, m0, kn * BK, CUR ? A0 : A1, pi); ++n_dma; }
+          else if (pi < PA + PB) {
+            if constexpr (B_KC) glds_kc_pass<BN, BK, NT>(B, g.b_ns, n0, kn * BK, CUR ? B0 : B1, pi - PA);
+            else glds_tile_pass<BN, BK, NT>(B, g.b_ks, n0, kn * BK, CUR ? B0 : B1, pi - PA);
+            ++n_dma;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+          for (int q = 0; q < WTN; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][t], fb[c][q][t], acc[i][q], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < WTM * WTN; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (m < n_dma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+      }
+    }
+    __syncthreads();
+    MD_KC_READ(CUR ^ 1, 0, 0)
+  };
+  static_assert(NP == 2 || NP == 4, "k-pair prefetch is written out for 16- and 32-deep tiles");
+  int64_t kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    ktile(MdInt<0>{}, kt + 1);
+    ktile(MdInt<1>{}, kt + 2 < nk ? kt + 2 : nk - 1);
+  }
+  if (kt < nk) ktile(MdInt<0>{}, nk - 1);
+#undef MD_KC_READ
+
+  if constexpr (EPI == 1) {   // bias + relu-sum + mask instead of C (md_epi_bias_relu); the mask goes through A0, 32 KiB at most
+    constexpr int NPASS = (BM * BN > BM * BK * 4) ? (BM * BN) / (BM * BK * 4) : 1;
+    __syncthreads();
+    md_epi_bias_relu<BM, BN, WM, WN, NPASS>(acc, g, m0, n0, reinterpret_cast<uint32_t *>(A0), B0);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < WTM; ++i)
 #pragma unroll
@@ -654,44 +833,73 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
 // (128x128x32, 8-wave 256x128 and 256x256 tiles were measured and dropped: profiles/r1_gemm_tile_ab.log, r2_gemm_small_grid_ab.log)
 enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_256x256x32, CFG_128x128x32, CFG_128x64x32, CFG_128x128_W8, CFG_COUNT };
 
-static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged) {
+static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged, bool dma_ok = false) {
   if (const char *e = getenv("MDHIP_GEMM_CFG")) {  // experiments only
     int v = atoi(e);
     if (v >= 0 && v < CFG_COUNT) return v;
   }
-  // Cost model over the four production tiles: a CU works through ceil(tiles / CUs) tiles of BM*BN
-  // outputs at the rate measured for that tile at 4096^3 (profiles/r1_gemm_tile_ab.log) — big tiles
-  // win on efficiency, small tiles on the partial last round of a grid that does not divide evenly
-  // (4097 rows: 3 rounds of 256x128 against 17 of 64x64, i.e. 0.80x the time).
+  // Cost model over the production tiles: a CU works through ceil(tiles / CUs) tiles of BM*BN outputs at the rate measured
+  // for that tile on full grids (profiles/r1_gemm_tile_ab.log, r2_gemm_small_grid_ab.log, r2_gemm_glds_ab.log) — big tiles
+  // win on efficiency, small tiles on the partial last round of a grid that does not divide evenly (4097 rows: 3 rounds of
+  // 256x128 against 17 of 64x64, i.e. 0.80x the time). `dma_ok`: operands aligned for the direct-to-LDS kernels, which
+  // take whole tiles and 32-deep k-tiles only; their rates apply to the candidates that divide the problem.
   if (((ga.M + 63) / 64) * ((ga.N + 63) / 64) * batch < MD_NUM_CUS && ga.K >= 1024) return CFG_64x64x16;  // split-K candidates
-  struct Cand { int cfg, bm, bn; double tf; };
-  static const Cand cands[] = {{CFG_256x128x16, 256, 128, 139.0}, {CFG_128x128x16, 128, 128, 133.0}, {CFG_128x128_W8, 128, 128, 133.0},
-                               {CFG_128x64x16, 128, 64, 126.0}, {CFG_64x64x16, 64, 64, 120.0}};
+  struct Cand { int cfg, bm, bn; double tf, tf_dma; };   // tf_dma = 0: no direct-to-LDS form of this tile
+  static const Cand cands[] = {{CFG_256x256x32, 256, 256, 0.0, 143.0}, {CFG_256x128x16, 256, 128, 139.0, 0.0}, {CFG_128x128x16, 128, 128, 133.0, 137.0},
+                               {CFG_128x128_W8, 128, 128, 133.0, 137.5}, {CFG_128x64x16, 128, 64, 126.0, 0.0}, {CFG_64x64x16, 64, 64, 120.0, 0.0}};
+  static const Cand cands_tn[] = {{CFG_256x256x32, 256, 256, 140.0, 141.5}, {CFG_256x128x16, 256, 128, 138.0, 0.0}, {CFG_128x128x32, 128, 128, 132.0, 133.5},
+                                  {CFG_128x128_W8, 128, 128, 134.0, 136.0}, {CFG_128x64x32, 128, 64, 126.7, 128.0}, {CFG_64x64x16, 64, 64, 120.0, 0.0}};
   int best = CFG_64x64x16;
   double best_t = 1e300;
-  if (vector_staged) {  // TN: 256x256x32 measured 141.9 against 138.2 TFLOP/s (profiles/r1_gemm_tile_ab.log)
-    const int64_t tiles = ((ga.M + 255) / 256) * ((ga.N + 255) / 256) * batch;
-    if (tiles >= MD_NUM_CUS) {
-      best_t = (double)((tiles + MD_NUM_CUS - 1) / MD_NUM_CUS) * 256 * 256 / 141.5;
-      best = CFG_256x256x32;
-    }
-  }
-  static const Cand cands_tn[] = {{CFG_256x128x16, 256, 128, 138.0}, {CFG_128x128x32, 128, 128, 132.0}, {CFG_128x128_W8, 128, 128, 134.0},
-                                  {CFG_128x64x32, 128, 64, 126.7}, {CFG_64x64x16, 64, 64, 120.0}};
-  for (int ci = 0; ci < 5; ++ci) {
+  for (int ci = 0; ci < 6; ++ci) {
     const Cand &c = vector_staged ? cands_tn[ci] : cands[ci];
+    const bool dma = dma_ok && c.tf_dma > 0.0 && ga.M % c.bm == 0 && ga.N % c.bn == 0 && ga.K % 32 == 0;
+    const double tf = dma ? c.tf_dma : c.tf;
+    if (tf <= 0.0) continue;
     const int64_t tiles = ((ga.M + c.bm - 1) / c.bm) * ((ga.N + c.bn - 1) / c.bn) * batch;
     const double rounds = (double)((tiles + MD_NUM_CUS - 1) / MD_NUM_CUS);
-    double t = rounds * c.bm * c.bn / c.tf;
-    if (tiles <= MD_NUM_CUS && c.cfg != CFG_128x128_W8) t /= 0.8;  // a lone four-wave block per CU (one wave per SIMD) cannot keep the matrix pipe fed
+    double t = rounds * c.bm * c.bn / tf;
+    // a lone four-wave block per CU (one wave per SIMD) cannot keep the matrix pipe fed — except the 256x256 tile, whose
+    // rate was measured that way (16 MFMAs per step and wave), and the eight-wave tile
+    if (tiles <= MD_NUM_CUS && c.cfg != CFG_128x128_W8 && c.cfg != CFG_256x256x32) t /= 0.8;
+    if (c.cfg == CFG_256x256x32 && tiles < MD_NUM_CUS) continue;   // (half-empty chip: never the best choice)
     if (t < best_t * 0.999) { best_t = t; best = c.cfg; }   // ties go to the larger tile (listed first)
   }
   return best;
 }
 
+// NN / NT with whole aligned tiles: the direct-to-LDS kernel for k-contiguous operands (k_gemm_f32_kc_glds); -1 = not applicable
+template <int BM, int BN, int WM, int WN, bool B_KC, int EPI = 0>
+static int launch_kc_glds(GemmArgs ga, int64_t batch, bool edge) {
+  constexpr int BK = 32;
+  if (edge || (ga.M % BM) || (ga.N % BN) || (ga.K % BK) || ga.a_ks != 1 || (B_KC ? ga.b_ks != 1 : ga.b_ns != 1)) return -1;
+  ga.tiles_m = (int)(ga.M / BM);
+  ga.tiles_n = (int)(ga.N / BN);
+  static const int sh = [] { const char *e = getenv("MDHIP_GEMM_SUPER"); return e ? atoi(e) : 8; }();
+  ga.super_h = (sh > 1 && ga.tiles_m >= sh && ga.tiles_n >= 8) ? sh : 0;
+  dim3 grid((unsigned)(ga.tiles_m * ga.tiles_n), 1, (unsigned)batch);
+  k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, EPI><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
+  return MD_LAUNCH_CHECK("matmul(f32 mfma, direct-to-LDS)");
+}
+
 template <bool A_KC, bool B_KC>
 static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
-  switch (pick_cfg(ga, batch, !A_KC && !B_KC)) {
+  // direct-to-LDS kernels: aligned operands whose vector axis has stride 1 (MDHIP_GEMM_GLDS=0, read at every launch, keeps
+  // the register-staged kernels: A/B runs and tests)
+  const char *e = getenv("MDHIP_GEMM_GLDS");
+  const bool dma_ok = (e ? atoi(e) != 0 : true) && !edge && !ga.stamp && (A_KC ? ga.a_ks == 1 : ga.a_ms == 1) && (B_KC ? ga.b_ks == 1 : ga.b_ns == 1) &&
+                      (A_KC || !B_KC);   // (A row-contiguous with B k-contiguous — "TT" — has no such kernel)
+  const int cfg = pick_cfg(ga, batch, !A_KC && !B_KC, dma_ok);
+  if constexpr (A_KC) {
+    if (dma_ok) {
+      int rc = -1;
+      if (cfg == CFG_256x256x32) rc = launch_kc_glds<256, 256, 2, 2, B_KC>(ga, batch, edge);
+      else if (cfg == CFG_128x128_W8) rc = launch_kc_glds<128, 128, 2, 4, B_KC>(ga, batch, edge);
+      else if (cfg == CFG_128x128x32 || cfg == CFG_128x128x16) rc = launch_kc_glds<128, 128, 2, 2, B_KC>(ga, batch, edge);
+      if (rc >= 0) return rc;
+    }
+  }
+  switch (cfg) {
     case CFG_64x64x16: return launch_cfg<64, 64, 16, 2, 2, A_KC, B_KC, 0>(ga, batch, edge);   // (2 MFMAs per step: nothing to interleave with; measured 6 % slower)
     case CFG_128x64x16: return launch_cfg<128, 64, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
     case CFG_256x128x16: return launch_cfg<256, 128, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
@@ -982,13 +1190,15 @@ __global__ void __launch_bounds__(MD_BLOCK) k_gemm_epi_finish(const float *__res
   if (threadIdx.x == 0) out[0] = sm[0];
 }
 
-template <int BM, int BN, int WM = 2, int WN = 2> static int launch_epi(GemmArgs ga) {
+template <int BM, int BN, int WM = 2, int WN = 2, bool DMA = false> static int launch_epi(GemmArgs ga) {
   const int64_t tiles = ((ga.M + BM - 1) / BM) * ((ga.N + BN - 1) / BN);
   void *partial = nullptr;
   MD_TRY(mdhip_alloc((size_t)tiles * sizeof(float), &partial));
   float *out = ga.partial;  // (the caller parked the 0-d result pointer here)
   ga.partial = (float *)partial;
-  int rc = launch_cfg<BM, BN, 16, WM, WN, true, false, BM == 64 ? 0 : 1, 1>(ga, 1, false);
+  int rc;
+  if constexpr (DMA) rc = launch_kc_glds<BM, BN, WM, WN, false, 1>(ga, 1, false);   // (the caller checked whole tiles and alignment)
+  else rc = launch_cfg<BM, BN, 16, WM, WN, true, false, BM == 64 ? 0 : 1, 1>(ga, 1, false);
   if (rc == MDHIP_OK) {
     k_gemm_epi_finish<<<1, MD_BLOCK, 0, md_stream()>>>((const float *)partial, tiles, out);
     rc = MD_LAUNCH_CHECK("matmul(bias+relu epilogue, finish)");
@@ -1027,8 +1237,16 @@ extern "C" int mdhip_matmul_bias_relu_sum(const mdhip_array *a, const mdhip_arra
   ga.bias = (const float *)bias->data;
   ga.mask = (uint8_t *)mask_out->data;
   ga.partial = (float *)sum_out->data;
-  // the plain kernel's tile choice, restricted to the tiles that divide the problem
-  const int cfg = pick_cfg(ga, 1, false);
+  // the plain kernel's tile choice (and with it the plain product's summation order: a mask recomputed from `a @ b + bias`
+  // agrees bit for bit), restricted to the tiles that divide the problem
+  const char *e = getenv("MDHIP_GEMM_GLDS");
+  const bool dma_ok = (e ? atoi(e) != 0 : true) && K % 32 == 0;
+  const int cfg = pick_cfg(ga, 1, false, dma_ok);
+  if (dma_ok) {
+    if (cfg == CFG_256x256x32 && M % 256 == 0 && N % 256 == 0) return launch_epi<256, 256, 2, 2, true>(ga);
+    if (cfg == CFG_128x128_W8 && M % 128 == 0 && N % 128 == 0) return launch_epi<128, 128, 2, 4, true>(ga);
+    if ((cfg == CFG_128x128x16 || cfg == CFG_128x128x32) && M % 128 == 0 && N % 128 == 0) return launch_epi<128, 128, 2, 2, true>(ga);
+  }
   if ((cfg == CFG_256x128x16 || cfg == CFG_256x256x32) && M % 256 == 0 && N % 128 == 0) return launch_epi<256, 128>(ga);
   if (cfg == CFG_128x128_W8 && M % 128 == 0 && N % 128 == 0) return launch_epi<128, 128, 2, 4>(ga);
   if (M % 128 == 0 && N % 128 == 0 && (cfg == CFG_128x128x16 || cfg == CFG_128x128x32 || cfg == CFG_256x128x16)) return launch_epi<128, 128>(ga);

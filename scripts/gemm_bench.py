@@ -14,7 +14,7 @@ from minidiff_amd import _capi, ndarray as nd  # noqa: E402
 CFGS = {0: "128x128x16", 1: "64x64x16", 2: "128x64x16", 3: "256x128x16", 4: "256x256x32 (TN)", 5: "128x128x32 (TN)", 6: "128x64x32 (TN)", 7: "128x128 8 waves"}
 if os.environ.get("GEMM_CFGS"):
     CFGS = {int(k): CFGS[int(k)] for k in os.environ["GEMM_CFGS"].split(",")}
-if os.environ.get("GEMM_GLDS_AB"):   # every config twice: register staging / direct-to-LDS staging (TN only; MDHIP_GEMM_GLDS is read per launch)
+if os.environ.get("GEMM_GLDS_AB"):   # every config twice: register staging / direct-to-LDS staging (MDHIP_GEMM_GLDS is read per launch)
     CFGS = {k + 100 * g: v + (" +glds" if g else "") for k, v in CFGS.items() for g in (0, 1)}
 
 

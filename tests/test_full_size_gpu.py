@@ -209,7 +209,7 @@ def test_every_gemm_tile_config_exact_on_integers(lib, on_gpu, tile, glds, monke
     assert on_gpu
     from minidiff_amd import ndarray as nd
     monkeypatch.setenv("MDHIP_GEMM_CFG", str(tile))
-    monkeypatch.setenv("MDHIP_GEMM_GLDS", glds)     # TN with 32-deep k-tiles: direct-to-LDS kernel / register-staged kernel
+    monkeypatch.setenv("MDHIP_GEMM_GLDS", glds)     # direct-to-LDS kernels (whole aligned tiles) / register-staged kernels
     rng = np.random.default_rng(100 + tile)
     prev = nd.set_lazy(False)
     try:
