@@ -214,12 +214,16 @@ def rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc):
         main = None
         # in lazy mode the weight-gradient matmul call also launches the fused pass that produces its operand:
         # price the GEMM on the calls that contain nothing else
-        gemm_kernel = "k_gemm_f32_mfma"
+        # (16-B aligned operands and whole tiles — every BASELINE shape — run the direct-to-LDS kernels; MDHIP_GEMM_GLDS=0 or a
+        # ragged shape the register-staged k_gemm_f32_mfma)
+        dma = os.environ.get("MDHIP_GEMM_GLDS", "1") != "0"
+        gemm_kernel = "k_gemm_f32_kc_glds (NN, NT) / k_gemm_f32_tn_glds (TN)" if dma else "k_gemm_f32_mfma"
         if workload == "cfg4" and lazy:
             # lazy mode defers the products: the forward GEMM runs inside the loss reduction with the bias / relu / sum
             # epilogue (bracket "sum_all", incl. its 1-block finish), the weight-gradient GEMM when W.grad is materialised
             durs = kernel_ms.get("sum_all", []) + kernel_ms.get("gemm_exec", [])
-            gemm_kernel = "k_gemm_f32_mfma (NN with the bias + relu-sum + mask epilogue, + finish) and k_gemm_f32_mfma (TN)"
+            gemm_kernel = ("k_gemm_f32_kc_glds (NN with the bias + relu-sum + mask epilogue, + finish) and k_gemm_f32_tn_glds (TN)" if dma
+                           else "k_gemm_f32_mfma (NN with the bias + relu-sum + mask epilogue, + finish) and k_gemm_f32_mfma (TN)")
         elif lazy:
             durs = kernel_ms.get("gemm_exec", [])
         elif workload == "cfg4":
@@ -227,7 +231,7 @@ def rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc):
         if durs:
             avg = _mean(durs)
             ach = flop_per_launch / (avg * 1e-3) / 1e12
-            committed = pmc_mean(pmc, "k_gemm_f32_mfma") if workload == "cfg2" and not size else None
+            committed = pmc_mean(pmc, "k_gemm_f32_") if workload == "cfg2" and not size else None
             main = {"bound": "mfma", "kernel": gemm_kernel, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
                     "traffic": None,  # not measured in this run (PMC passes need the profiler)

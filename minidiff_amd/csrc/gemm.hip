@@ -420,7 +420,10 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);
   constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NSTEP = BK / 2;
-  constexpr int PPS = (PA + PB + NSTEP / 2 - 1) / (NSTEP / 2);   // DMA pieces per step: all of them inside the first half of the k-tile
+#ifndef MD_TN_DMA_STEPS
+#define MD_TN_DMA_STEPS (NSTEP / 2)
+#endif
+  constexpr int PPS = (PA + PB + MD_TN_DMA_STEPS - 1) / (MD_TN_DMA_STEPS);   // DMA pieces per step: all of them early in the k-tile
   __shared__ float A0[BK][BM];
   __shared__ float A1[BK][BM];
   __shared__ float B0[BK][BN];
@@ -551,7 +554,10 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);
   constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NSTEP = BK / 2, NP = BK / 8, KH = BK / 16;
-  constexpr int PPS = (PA + PB + NSTEP / 2 - 1) / (NSTEP / 2);
+#ifndef MD_KC_DMA_STEPS
+#define MD_KC_DMA_STEPS 4
+#endif
+  constexpr int PPS = (PA + PB + MD_KC_DMA_STEPS - 1) / (MD_KC_DMA_STEPS);
   static_assert(NP % 2 == 0, "an even number of k-pairs per tile (fragment double buffer)");
   __shared__ __attribute__((aligned(16))) float A0[BM * BK];
   __shared__ __attribute__((aligned(16))) float A1[BM * BK];
@@ -594,6 +600,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   const int64_t nk = g.K / BK;
+  unsigned long long st_c = 0, st_r = 0;   // diagnostic stamps (MDHIP_GEMM_STAMP=1), as in k_gemm_f32_mfma
+  if (g.stamp) { st_c = __builtin_amdgcn_s_memtime(); st_r = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll
   for (int i = 0; i < PA; ++i) glds_kc_pass<BM, BK, NT>(A, g.a_ms, m0, 0, A0, i);
 #pragma unroll
@@ -648,10 +656,17 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
         for (int i = 0; i < WTM; ++i)
 #pragma unroll
           for (int q = 0; q < WTN; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][t], fb[c][q][t], acc[i][q], 0, 0, 0);
+        // the next pair's fragment reads go behind the FIRST MFMAs of this pair, one each (with a read slot behind every MFMA
+        // of the pair the scheduler parked the reads at its end, right in front of the wait for them)
+        constexpr int NRD = WTM + (B_KC ? WTN : 4 * WTN), MPS = WTM * WTN;
+#ifndef MD_KC_RD
+#define MD_KC_RD (MPS >= 8 ? 0 : 1)
+#endif
+        const int rd_slots = MD_KC_RD == 0 ? MPS : MD_KC_RD == 2 ? 0 : j + 1 < NP ? (NRD - t * MPS < 0 ? 0 : (NRD - t * MPS > MPS ? MPS : NRD - t * MPS)) : 0;
 #pragma unroll
-        for (int m = 0; m < WTM * WTN; ++m) {
+        for (int m = 0; m < MPS; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (m < rd_slots) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           if (m < n_dma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
       }
@@ -668,6 +683,10 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
   if (kt < nk) ktile(MdInt<0>{}, nk - 1);
 #undef MD_KC_READ
 
+  if (g.stamp && threadIdx.x == 0) {
+    g.stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c;
+    g.stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r;
+  }
   if constexpr (EPI == 1) {   // bias + relu-sum + mask instead of C (md_epi_bias_relu); the mask goes through A0, 32 KiB at most
     constexpr int NPASS = (BM * BN > BM * BK * 4) ? (BM * BN) / (BM * BK * 4) : 1;
     __syncthreads();
@@ -748,8 +767,8 @@ struct StampDump {
     std::sort(ghz.begin(), ghz.end());
     std::sort(us.begin(), us.end());
     if (!ghz.empty())
-      fprintf(stderr, "[mdhip] last gemm %dx%dx%d: in-kernel clock median %.3f GHz (min %.3f, max %.3f) over %zu blocks; block main loop median %.1f us (min %.1f, max %.1f)\n",
-              bm, bn, bk, ghz[ghz.size() / 2], ghz.front(), ghz.back(), ghz.size(), us[us.size() / 2], us.front(), us.back());
+      fprintf(stderr, "[mdhip] last gemm %dx%dx%d: in-kernel clock median %.3f GHz (min %.3f, max %.3f) over %zu blocks; block main loop median %.1f us (min %.1f, p10 %.1f, p90 %.1f, max %.1f)\n",
+              bm, bn, bk, ghz[ghz.size() / 2], ghz.front(), ghz.back(), ghz.size(), us[us.size() / 2], us.front(), us[us.size() / 10], us[us.size() * 9 / 10], us.back());
   }
 };
 
@@ -878,6 +897,11 @@ static int launch_kc_glds(GemmArgs ga, int64_t batch, bool edge) {
   static const int sh = [] { const char *e = getenv("MDHIP_GEMM_SUPER"); return e ? atoi(e) : 8; }();
   ga.super_h = (sh > 1 && ga.tiles_m >= sh && ga.tiles_n >= 8) ? sh : 0;
   dim3 grid((unsigned)(ga.tiles_m * ga.tiles_n), 1, (unsigned)batch);
+  static const bool stamp = [] { const char *e = getenv("MDHIP_GEMM_STAMP"); return e && atoi(e) == 1; }();
+  if (stamp && (size_t)grid.x * grid.z <= StampDump::kMax) {
+    ga.stamp = StampDump::get().buffer();
+    StampDump::get().note(BM, BN, BK, (size_t)grid.x * grid.z);
+  }
   k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, EPI><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
   return MD_LAUNCH_CHECK("matmul(f32 mfma, direct-to-LDS)");
 }

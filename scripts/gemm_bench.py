@@ -37,7 +37,8 @@ def main():
         for rnd in range(3):
             for cfg in CFGS:
                 os.environ["MDHIP_GEMM_CFG"] = str(cfg % 100)
-                os.environ["MDHIP_GEMM_GLDS"] = str(cfg // 100)
+                if os.environ.get("GEMM_GLDS_AB"):
+                    os.environ["MDHIP_GEMM_GLDS"] = str(cfg // 100)
                 combos = (("NN", A, B), ("NT", A, Bt.T), ("TN", At.T, B)) + ((("TT", At.T, Bt.T),) if os.environ.get("GEMM_TT") else ())
                 for tag, a, b in combos:
                     nd.matmul(a, b)  # warm
@@ -57,7 +58,7 @@ def main():
         for cfg, name in CFGS.items():
             print("   %-22s " % name + "  ".join("%s med %6.1f max %6.1f TF" % (t, sorted(res[(cfg, t)])[1], max(res[(cfg, t)])) for t in (("NN", "NT", "TN", "TT") if os.environ.get("GEMM_TT") else ("NN", "NT", "TN"))))
     del os.environ["MDHIP_GEMM_CFG"]
-    del os.environ["MDHIP_GEMM_GLDS"]
+    os.environ.pop("MDHIP_GEMM_GLDS", None)
 
 
 if __name__ == "__main__":
