@@ -467,6 +467,63 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
   for (int i = 0; i < PB; ++i) glds_tile_pass<BN, BK, NT>(B, g.b_ks, n0, 0, &B0[0][0], i);
   __syncthreads();
 
+#ifndef MD_TN_PAIR
+#define MD_TN_PAIR 1
+#endif
+#if MD_TN_PAIR
+  // fragments for TWO steps (4 k) per LDS instruction: rows 4p+h and 4p+2+h of the [k][row] image lie 2*ROWS floats apart, a
+  // multiple of 64 dwords, so the two loads of a lane fuse into one ds_read2st64_b32 — half the LDS read instructions; MFMA t of
+  // the pair takes k = 4p+2t (lanes 0-31) and 4p+2t+1 (lanes 32-63): the plain k order
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int NPR = BK / 4;
+  f32x2 fa[2][WTM], fb[2][WTN];
+#define MD_TN_READ(BUF, p, c)                                                                                          \
+  {                                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < WTM; ++i) {                                                                  \
+      fa[c][i][0] = ((BUF) ? A1 : A0)[4 * (p) + h][am + i * 32];                                                       \
+      fa[c][i][1] = ((BUF) ? A1 : A0)[4 * (p) + 2 + h][am + i * 32];                                                   \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < WTN; ++q) {                                                                  \
+      fb[c][q][0] = ((BUF) ? B1 : B0)[4 * (p) + h][bn + q * 32];                                                       \
+      fb[c][q][1] = ((BUF) ? B1 : B0)[4 * (p) + 2 + h][bn + q * 32];                                                   \
+    }                                                                                                                  \
+  }
+  MD_TN_READ(0, 0, 0)
+  auto ktile = [&](auto curc, int64_t kn) {
+    constexpr int CUR = decltype(curc)::value;
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) {
+      const int c = p & 1;
+      if (p + 1 < NPR) MD_TN_READ(CUR, p + 1, c ^ 1)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int sidx = 2 * p + t;
+        int n_dma = 0;
+#pragma unroll
+        for (int q = 0; q < PPS; ++q) {
+          const int pi = sidx * PPS + q;
+          if (pi < PA) { glds_tile_pass<BM, BK, NT>(A, g.a_ks, m0, kn * BK, CUR ? &A0[0][0] : &A1[0][0], pi); ++n_dma; }
+          else if (pi < PA + PB) { glds_tile_pass<BN, BK, NT>(B, g.b_ks, n0, kn * BK, CUR ? &B0[0][0] : &B1[0][0], pi - PA); ++n_dma; }
+        }
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][t], fb[c][j][t], acc[i][j], 0, 0, 0);
+        constexpr int NRD = WTM + WTN, MPS = WTM * WTN;
+        const int rd_slots = MPS >= 8 ? MPS : p + 1 < NPR ? (NRD - t * MPS < 0 ? 0 : (NRD - t * MPS > MPS ? MPS : NRD - t * MPS)) : 0;
+#pragma unroll
+        for (int m = 0; m < MPS; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (m < rd_slots) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (m < n_dma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+      }
+    }
+    __syncthreads();
+    MD_TN_READ(CUR ^ 1, 0, 0)
+  };
+#undef MD_TN_READ
+#else
   float fa[2][WTM], fb[2][WTN];
 #pragma unroll
   for (int i = 0; i < WTM; ++i) fa[0][i] = A0[h][am + i * 32];
@@ -509,6 +566,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < WTN; ++j) fb[0][j] = CUR ? B0[h][bn + j * 32] : B1[h][bn + j * 32];
   };
+#endif
   int64_t kt = 0;
   for (; kt + 1 < nk; kt += 2) {
     ktile(MdInt<0>{}, kt + 1);
