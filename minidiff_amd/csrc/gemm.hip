@@ -673,7 +673,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
   // fragments of k-pair j out of buffer BUF (compile-time) into register set c
 #define MD_KC_READ(BUF, j, c)                                                                                                   \
   {                                                                                                                             \
-    constexpr int joff = ((j) >> 1) * 256 + (((2 * (j)) & 3) * 64);                                                             \
+    const int joff = ((j) >> 1) * 256 + (((2 * (j)) & 3) * 64);   /* (a constant once the pair loop is unrolled) */             \
     _Pragma("unroll") for (int i = 0; i < WTM; ++i)                                                                             \
       fa[c][i] = *reinterpret_cast<const f32x4 *>(((BUF) ? A1 : A0) + abase + i * (2 * KH * 256) + joff);                       \
     _Pragma("unroll") for (int q = 0; q < WTN; ++q) {                                                                           \
@@ -690,12 +690,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int c = j & 1;
-      if (j + 1 < NP) {
-        // (j + 1 as a constant expression: the loop is fully unrolled, but a macro argument must be usable in constexpr context)
-        if (j == 0) MD_KC_READ(CUR, 1, 1)
-        if (NP > 2 && j == 1) MD_KC_READ(CUR, 2, 0)
-        if (NP > 2 && j == 2) MD_KC_READ(CUR, 3, 1)
-      }
+      if (j + 1 < NP) MD_KC_READ(CUR, j + 1, c ^ 1)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int sidx = j * 4 + t;
@@ -732,7 +727,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
     __syncthreads();
     MD_KC_READ(CUR ^ 1, 0, 0)
   };
-  static_assert(NP == 2 || NP == 4, "k-pair prefetch is written out for 16- and 32-deep tiles");
   int64_t kt = 0;
   for (; kt + 1 < nk; kt += 2) {
     ktile(MdInt<0>{}, kt + 1);
@@ -946,9 +940,8 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged, bool 
 }
 
 // NN / NT with whole aligned tiles: the direct-to-LDS kernel for k-contiguous operands (k_gemm_f32_kc_glds); -1 = not applicable
-template <int BM, int BN, int WM, int WN, bool B_KC, int EPI = 0>
+template <int BM, int BN, int WM, int WN, bool B_KC, int EPI = 0, int BK = 32>
 static int launch_kc_glds(GemmArgs ga, int64_t batch, bool edge) {
-  constexpr int BK = 32;
   if (edge || (ga.M % BM) || (ga.N % BN) || (ga.K % BK) || ga.a_ks != 1 || (B_KC ? ga.b_ks != 1 : ga.b_ns != 1)) return -1;
   ga.tiles_m = (int)(ga.M / BM);
   ga.tiles_n = (int)(ga.N / BN);
@@ -976,7 +969,7 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
     if (dma_ok) {
       int rc = -1;
       if (cfg == CFG_256x256x32) rc = launch_kc_glds<256, 256, 2, 2, B_KC>(ga, batch, edge);
-      else if (cfg == CFG_128x128_W8) rc = launch_kc_glds<128, 128, 2, 4, B_KC>(ga, batch, edge);
+      else if (cfg == CFG_128x128_W8) rc = launch_kc_glds<128, 128, 2, 4, B_KC>(ga, batch, edge);   // (64-deep k-tiles: no gain, r2_gemm_glds_ab.log)
       else if (cfg == CFG_128x128x32 || cfg == CFG_128x128x16) rc = launch_kc_glds<128, 128, 2, 2, B_KC>(ga, batch, edge);
       if (rc >= 0) return rc;
     }
