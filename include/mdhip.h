@@ -161,6 +161,13 @@ int mdhip_event_create(void **ev_out);
 int mdhip_event_record(void *ev);
 int mdhip_event_elapsed_ms(void *start, void *stop, float *ms_out); /* SYNCHRONISES on stop */
 int mdhip_event_destroy(void *ev);
+/* Kernel-attached timing (bench.py): the NEXT f32 matrix-core GEMM kernel this thread launches (mdhip_matmul,
+ * mdhip_matmul_bias_relu_sum) records `start` when it begins and `stop` when it ends — timestamps of the dispatch itself
+ * (hipExtLaunchKernel), with no marker packets between kernels (a mdhip_event_record bracket costs ~5 us of stream
+ * time per marker). mdhip_event_attach_cancel drops a pending attachment and says whether there was one: a call that
+ * launched no such kernel (deferred, split-K, float64, integer) left it pending, and the events were never recorded. */
+int mdhip_event_attach_next(void *start, void *stop);
+int mdhip_event_attach_cancel(int *was_pending_out);
 
 /* ======================= hipGraph capture / replay ========================== */
 /* Capture everything enqueued on the library's stream between begin and end into a

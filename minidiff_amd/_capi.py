@@ -104,6 +104,8 @@ _PROTOTYPES = {
     "mdhip_event_record": [C.c_void_p],
     "mdhip_event_elapsed_ms": [C.c_void_p, C.c_void_p, _P(C.c_float)],
     "mdhip_event_destroy": [C.c_void_p],
+    "mdhip_event_attach_next": [C.c_void_p, C.c_void_p],
+    "mdhip_event_attach_cancel": [_P(C.c_int)],
     "mdhip_graph_begin": [],
     "mdhip_graph_end": [_P(C.c_void_p)],
     "mdhip_graph_launch": [C.c_void_p],

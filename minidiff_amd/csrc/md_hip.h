@@ -6,6 +6,7 @@
 #include "md_dispatch.h"
 
 hipStream_t md_stream();
+bool md_prof_take(hipEvent_t *start, hipEvent_t *stop);   // bench timing: events for the next GEMM kernel, if any were attached
 int md_hip_check(hipError_t e, const char *what);
 
 #define MD_LAUNCH_CHECK(name) md_hip_check(hipGetLastError(), name)

@@ -67,6 +67,16 @@ int release_cache_locked(State &s) {
 
 hipStream_t md_stream() { return S().stream; }
 
+// events to attach to the next GEMM kernel (mdhip_event_attach_next)
+static thread_local hipEvent_t t_prof_start = nullptr, t_prof_stop = nullptr;
+bool md_prof_take(hipEvent_t *start, hipEvent_t *stop) {
+  if (!t_prof_start) return false;
+  *start = t_prof_start;
+  *stop = t_prof_stop;
+  t_prof_start = t_prof_stop = nullptr;
+  return true;
+}
+
 int md_hip_check(hipError_t e, const char *what) {
   if (e == hipSuccess) return MDHIP_OK;
   return md_fail(e == hipErrorOutOfMemory ? MDHIP_EMEMORY : MDHIP_ERUNTIME, "%s: %s", what, hipGetErrorString(e));
@@ -290,6 +300,19 @@ int mdhip_event_elapsed_ms(void *a, void *b, float *ms) {
   return md_hip_check(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b), "hipEventElapsedTime");
 }
 int mdhip_event_destroy(void *ev) { return md_hip_check(hipEventDestroy((hipEvent_t)ev), "hipEventDestroy"); }
+
+// kernel-attached timing: consumed by the GEMM launchers through md_prof_take (md_hip.h)
+int mdhip_event_attach_next(void *start, void *stop) {
+  if (!start || !stop) return md_fail(MDHIP_EVALUE, "event_attach_next: two events");
+  t_prof_start = (hipEvent_t)start;
+  t_prof_stop = (hipEvent_t)stop;
+  return MDHIP_OK;
+}
+int mdhip_event_attach_cancel(int *was_pending) {
+  if (was_pending) *was_pending = t_prof_start != nullptr;
+  t_prof_start = t_prof_stop = nullptr;
+  return MDHIP_OK;
+}
 
 // ============================ hipGraph ==========================================
 int mdhip_graph_begin(void) {

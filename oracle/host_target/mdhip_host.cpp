@@ -175,6 +175,27 @@ int mdhip_event_elapsed_ms(void *a, void *b, float *ms) {
   return MDHIP_OK;
 }
 int mdhip_event_destroy(void *ev) { delete (HostEvent *)ev; return MDHIP_OK; }
+// kernel-attached timing: the double stamps the two events around the next f32 product it computes
+static thread_local HostEvent *t_prof_start = nullptr, *t_prof_stop = nullptr;
+int mdhip_event_attach_next(void *start, void *stop) {
+  if (!start || !stop) return md_fail(MDHIP_EVALUE, "event_attach_next: two events");
+  t_prof_start = (HostEvent *)start; t_prof_stop = (HostEvent *)stop;
+  return MDHIP_OK;
+}
+int mdhip_event_attach_cancel(int *was_pending) {
+  if (was_pending) *was_pending = t_prof_start != nullptr;
+  t_prof_start = t_prof_stop = nullptr;
+  return MDHIP_OK;
+}
+namespace {
+struct ProfScope {   // (the device library attaches to f32 matrix-core kernels only; so does the double)
+  HostEvent *e0 = nullptr, *e1 = nullptr;
+  explicit ProfScope(bool f32) {
+    if (f32 && t_prof_start) { e0 = t_prof_start; e1 = t_prof_stop; t_prof_start = t_prof_stop = nullptr; e0->t = std::chrono::steady_clock::now(); }
+  }
+  ~ProfScope() { if (e1) e1->t = std::chrono::steady_clock::now(); }
+};
+}  // namespace
 
 // graphs: the double executes immediately, so "capture" records nothing and replay cannot
 // re-run anything; it only accepts the call sequence (tests of the Python wrapper's state
@@ -215,6 +236,7 @@ int mdhip_reduce(int op, const mdhip_array *x, const mdhip_array *out, uint32_t 
   return md_reduce_dispatch<HostExec>(op, x, out, mask);
 }
 int mdhip_matmul(const mdhip_array *a, const mdhip_array *b, const mdhip_array *c) {
+  ProfScope prof(a && a->dtype == MDHIP_F32);
   return md_matmul_dispatch<HostExec>(a, b, c);
 }
 // fused GEMM + bias + relu-sum + mask: plain loops here (k-ordered float fma chain per element, as the MFMA kernel)
@@ -234,6 +256,7 @@ int mdhip_matmul_bias_relu_sum(const mdhip_array *a, const mdhip_array *b, const
     return md_fail(MDHIP_EVALUE, "matmul_bias_relu_sum: shapes do not agree");
   if ((M % 64) || (N % 64) || (K % 16))   // (the double keeps the product's notion of "covered", so that both paths get exercised)
     return md_fail(MDHIP_EVALUE, "matmul_bias_relu_sum: shape not covered by the fused kernel");
+  ProfScope prof(true);
   const float *A = (const float *)a->data, *B = (const float *)b->data, *bv = (const float *)bias->data;
   uint8_t *mk = (uint8_t *)mask_out->data;
   float total = 0.0f;
