@@ -16,7 +16,8 @@ With N > 1 (one rank per GPU, launched by torch.distributed.run) the default
 workload is BASELINE's configs[3] (cfg4): the global batch of 8192 rows is split
 over the ranks (strong scaling), [W.grad || b.grad] is summed by RCCL all-reduce
 in row panels that leave while the weight-gradient GEMM is still running, and
-`tensors_per_s` = 8192 x sweeps/s. `--workload cfg2` at N > 1 is the weak-scaling
+`tensors_per_s` = 8192 x sweeps/s, and `single_gpu_same_workload` holds the un-sharded cfg4 sweep timed on ONE GPU in the
+same job (the driver's N = 1 run is cfg2: another workload). `--workload cfg2` at N > 1 is the weak-scaling
 variant (every rank owns its own 4096-row block A_r; B.grad all-reduced); it is
 also run after the headline and reported under "secondary".
 
@@ -328,6 +329,7 @@ def main():
     # rehearse it on a one-GPU box
     force_dist = os.environ.get("MDHIP_BENCH_FORCE_DIST") == "1"
     use_dist = world > 1 or force_dist
+    WORLD, RANK, USE_DIST = world, rank, use_dist   # (run() shadows the lower-case names in its solo mode)
     if args.workload is None:
         args.workload = "cfg4" if use_dist else "cfg2"
     dist = torch = None
@@ -416,9 +418,12 @@ def main():
                 kind = "rccl-torch"
         return comm, kind
 
-    def run(workload, lazy, steps, warmup, graph=False, size=0, keep=None):
+    def run(workload, lazy, steps, warmup, graph=False, size=0, keep=None, solo=False):
         """One workload: pre-roll, W warm-up sweeps, K timed sweeps between barriers, max over ranks.
-        `keep`: dict carrying (state, step) between the eager and the lazy run of one workload."""
+        `keep`: dict carrying (state, step) between the eager and the lazy run of one workload.
+        `solo` (N > 1 jobs): every rank runs the UN-sharded workload on its own GPU with no collective, and the time is the
+        calling rank's own — the same-job N = 1 figure of the workload the N > 1 headline is quoted on."""
+        world, rank, use_dist = (1, 0, False) if solo else (WORLD, RANK, USE_DIST)
         prev_lazy = nd.set_lazy(bool(lazy))
         kw = {}
         if workload == "cfg2":
@@ -439,7 +444,7 @@ def main():
             state, step = workloads.MAKERS[workload](md, **kw)
             if keep is not None:
                 keep["state"], keep["step"] = state, step
-        comm, comm_kind = make_comm(workload)
+        comm, comm_kind = (None, "none") if solo else make_comm(workload)
         sync = dp.GradSync(md, state["params"] if workload == "cfg4" else state["params"][:1], comm, force=force_dist,
                            overlap=os.environ.get("MDHIP_DP_OVERLAP", "1") != "0")
 
@@ -575,6 +580,20 @@ def main():
 
     head = run(args.workload, args.lazy, args.steps, args.warmup, graph=args.graph, size=args.size)
     event_overhead_ms = timer.empty_bracket_ms()
+    # N > 1: the headline is the batch-sharded cfg4 sweep, the driver's N = 1 run is cfg2 — so the same job also times the
+    # UN-sharded sweep of the headline workload on one GPU (every rank on its own card, no collective; rank 0's figure)
+    solo = None
+    if world > 1 and not args.graph:
+        gc.collect()
+        lib.empty_cache()
+        r1 = run(args.workload, args.lazy, min(args.steps, 10), min(args.warmup, 2), size=args.size, solo=True)
+        solo = {"value": r1["value"], "unit": "passes/s", "ms_per_step": r1["ms_per_step"], "n_gpus": 1,
+                "workload": r1["config"]["workload"],
+                "note": "the headline workload un-sharded on ONE GPU, timed in this job (all ranks run it at once, no collective)"}
+        if "tensors_per_s" in r1:
+            solo["tensors_per_s"] = r1["tensors_per_s"]
+        gc.collect()
+        lib.empty_cache()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -624,6 +643,8 @@ def main():
         }
         if "tensors_per_s" in head:
             line["tensors_per_s"] = head["tensors_per_s"]
+        if solo is not None:
+            line["single_gpu_same_workload"] = solo
         if args.workload != "cfg2" or args.lazy:
             line["kernels"] = head["kernels"]
         # per-kernel durations are HIP-event brackets around one backend call: they include the markers' own cost

@@ -63,3 +63,6 @@ def test_bench_two_ranks_control_flow_over_gloo(lib, on_gpu):
     assert d["config"]["allreduce_overlapped_sweeps"] == d["preroll_sweeps"] + 1 + 2 + 10 + 2   # (+ ten single synchronised sweeps)
     sec = d["secondary"]["cfg2_weak"]
     assert "error" not in sec and sec["scaling"] == "weak" and sec["config"]["collective"] == "gloo-host(test)" and sec["value"] > 0
+    # the same job's N = 1 figure of the headline workload (un-sharded batch, no collective)
+    solo = d["single_gpu_same_workload"]
+    assert solo["n_gpus"] == 1 and solo["value"] > 0 and solo["workload"].startswith("cfg4") and solo["tensors_per_s"] == pytest.approx(64 * solo["value"])
