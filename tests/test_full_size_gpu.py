@@ -237,3 +237,36 @@ def test_every_gemm_tile_config_exact_on_integers(lib, on_gpu, tile, glds, monke
         assert abs(float(loss.get()) - np.where(zr > 0, zr, 0).sum()) <= 1e-6 * np.abs(zr).sum(), tile
     finally:
         nd.set_lazy(prev)
+
+
+def test_direct_to_lds_gemm_random_aligned_shapes(lib, on_gpu):
+    """Random whole-tile shapes, batches, aligned sub-views and transposed operands through the tile picker (no forced config):
+    integer-valued operands, so every product must EQUAL NumPy's; a float case per shape within 2e-6."""
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    rng = np.random.default_rng(2026)
+    prev = nd.set_lazy(False)
+    try:
+        for case in range(36):
+            M, N = (int(rng.choice([128, 256, 384, 512, 768, 1024])) for _ in range(2))
+            K = int(rng.choice([32, 64, 96, 160, 256, 480, 1024]))
+            batch = int(rng.choice([0, 0, 0, 2, 3]))
+            lay = str(rng.choice(["NN", "NT", "TN", "TT"]))
+            lead = (batch,) if batch else ()
+            # operands cut out of larger arrays at 16-B aligned offsets (row stride stays a multiple of 4 floats)
+            pad_r, pad_c = int(rng.choice([0, 4, 8])), int(rng.choice([0, 4, 12]))
+            def make(rows, cols, transposed):
+                r, c = (cols, rows) if transposed else (rows, cols)
+                big = rng.integers(-3, 4, lead + (r + pad_r, c + pad_c)).astype(np.float32)
+                dev = nd.asarray(big)
+                sl = (slice(None),) * len(lead) + (slice(pad_r, pad_r + r), slice(pad_c, pad_c + c))
+                h, d = big[sl], dev[sl]
+                return (np.swapaxes(h, -1, -2), nd.swapaxes(d, -1, -2)) if transposed else (h, d)
+            (ha, da), (hb, db) = make(M, K, lay[0] == "T"), make(K, N, lay[1] == "T")
+            got = nd.matmul(da, db).get()
+            assert np.array_equal(got, np.matmul(ha.astype(np.float64), hb.astype(np.float64))), (case, M, K, N, batch, lay, pad_r, pad_c)
+            fa, fb = rng.standard_normal((M, K), dtype=np.float32), rng.standard_normal((K, N), dtype=np.float32)
+            ref = fa.astype(np.float64) @ fb
+            assert _rel(nd.matmul(nd.asarray(fa), nd.asarray(fb)).get(), ref) < 2e-6, (case, M, K, N)
+    finally:
+        nd.set_lazy(prev)
