@@ -426,10 +426,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);
   constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NSTEP = BK / 2;
-#ifndef MD_TN_DMA_STEPS
-#define MD_TN_DMA_STEPS (NSTEP / 2)
-#endif
-  constexpr int PPS = (PA + PB + MD_TN_DMA_STEPS - 1) / (MD_TN_DMA_STEPS);   // DMA pieces per step: all of them early in the k-tile
+  constexpr int DMA_STEPS = NSTEP / 2;                        // the next tile's DMA pieces are issued within the first half of the k-tile
+  constexpr int PPS = (PA + PB + DMA_STEPS - 1) / DMA_STEPS;  // (4 / 2 steps instead of 8: no difference for this kernel, r2_gemm_glds_ab.log)
   __shared__ float A0[BK][BM];
   __shared__ float A1[BK][BM];
   __shared__ float B0[BK][BN];
@@ -473,10 +471,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
   for (int i = 0; i < PB; ++i) glds_tile_pass<BN, BK, NT>(B, g.b_ks, n0, 0, &B0[0][0], i);
   __syncthreads();
 
-#ifndef MD_TN_PAIR
-#define MD_TN_PAIR 1
-#endif
-#if MD_TN_PAIR
   // fragments for TWO steps (4 k) per LDS instruction: rows 4p+h and 4p+2+h of the [k][row] image lie 2*ROWS floats apart, a
   // multiple of 64 dwords, so the two loads of a lane fuse into one ds_read2st64_b32 — half the LDS read instructions; MFMA t of
   // the pair takes k = 4p+2t (lanes 0-31) and 4p+2t+1 (lanes 32-63): the plain k order
@@ -529,50 +523,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
     MD_TN_READ(CUR ^ 1, 0, 0)
   };
 #undef MD_TN_READ
-#else
-  float fa[2][WTM], fb[2][WTN];
-#pragma unroll
-  for (int i = 0; i < WTM; ++i) fa[0][i] = A0[h][am + i * 32];
-#pragma unroll
-  for (int j = 0; j < WTN; ++j) fb[0][j] = B0[h][bn + j * 32];
-
-  // one k-tile out of buffer CUR; tile `kn` (clamped by the caller: a redundant last prefetch is never read) goes to the other one
-  auto ktile = [&](auto curc, int64_t kn) {
-    constexpr int CUR = decltype(curc)::value;
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const int c = (kk >> 1) & 1, sidx = kk >> 1;
-      if (kk + 2 < BK) {
-#pragma unroll
-        for (int i = 0; i < WTM; ++i) fa[c ^ 1][i] = CUR ? A1[kk + 2 + h][am + i * 32] : A0[kk + 2 + h][am + i * 32];
-#pragma unroll
-        for (int j = 0; j < WTN; ++j) fb[c ^ 1][j] = CUR ? B1[kk + 2 + h][bn + j * 32] : B0[kk + 2 + h][bn + j * 32];
-      }
-      int n_dma = 0;
-#pragma unroll
-      for (int q = 0; q < PPS; ++q) {
-        const int pi = sidx * PPS + q;
-        if (pi < PA) { glds_tile_pass<BM, BK, NT>(A, g.a_ks, m0, kn * BK, CUR ? &A0[0][0] : &A1[0][0], pi); ++n_dma; }
-        else if (pi < PA + PB) { glds_tile_pass<BN, BK, NT>(B, g.b_ks, n0, kn * BK, CUR ? &B0[0][0] : &B1[0][0], pi - PA); ++n_dma; }
-      }
-#pragma unroll
-      for (int i = 0; i < WTM; ++i)
-#pragma unroll
-        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int m = 0; m < WTM * WTN; ++m) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // one LDS read (next step's fragments)
-        if (m < n_dma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // one LDS-DMA piece of the next tile
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < WTM; ++i) fa[0][i] = CUR ? A0[h][am + i * 32] : A1[h][am + i * 32];
-#pragma unroll
-    for (int j = 0; j < WTN; ++j) fb[0][j] = CUR ? B0[h][bn + j * 32] : B1[h][bn + j * 32];
-  };
-#endif
   int64_t kt = 0;
   for (; kt + 1 < nk; kt += 2) {
     ktile(MdInt<0>{}, kt + 1);
@@ -618,10 +568,10 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);
   constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NSTEP = BK / 2, NP = BK / 8, KH = BK / 16;
-#ifndef MD_KC_DMA_STEPS
-#define MD_KC_DMA_STEPS 4
-#endif
-  constexpr int PPS = (PA + PB + MD_KC_DMA_STEPS - 1) / (MD_KC_DMA_STEPS);
+  // the next tile's DMA pieces go out within the first DMA_STEPS steps of the k-tile (16 steps at BK 32); same-box A/B at 4096^3 NT,
+  // r2_gemm_glds_ab.log: 16 steps 138.9 | 8: 144.6 | 4: 146.0 | 3: 145.5 | 2: 143.8 | 1: 140.4 TFLOP/s
+  constexpr int DMA_STEPS = 4;
+  constexpr int PPS = (PA + PB + DMA_STEPS - 1) / DMA_STEPS;
   static_assert(NP % 2 == 0, "an even number of k-pairs per tile (fragment double buffer)");
   __shared__ __attribute__((aligned(16))) float A0[BM * BK];
   __shared__ __attribute__((aligned(16))) float A1[BM * BK];
@@ -718,10 +668,10 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
         // the next pair's fragment reads go behind the FIRST MFMAs of this pair, one each (with a read slot behind every MFMA
         // of the pair the scheduler parked the reads at its end, right in front of the wait for them)
         constexpr int NRD = WTM + (B_KC ? WTN : 4 * WTN), MPS = WTM * WTN;
-#ifndef MD_KC_RD
-#define MD_KC_RD (MPS >= 8 ? 0 : 1)
-#endif
-        const int rd_slots = MD_KC_RD == 0 ? MPS : MD_KC_RD == 2 ? 0 : j + 1 < NP ? (NRD - t * MPS < 0 ? 0 : (NRD - t * MPS > MPS ? MPS : NRD - t * MPS)) : 0;
+        // tiles with >= 8 MFMAs per step: a read slot behind EVERY MFMA (measured best there); smaller ones: only behind the
+        // first MFMAs of the pair, one per read
+        constexpr bool RD_EVERY = MPS >= 8;
+        const int rd_slots = RD_EVERY ? MPS : j + 1 < NP ? (NRD - t * MPS < 0 ? 0 : (NRD - t * MPS > MPS ? MPS : NRD - t * MPS)) : 0;
 #pragma unroll
         for (int m = 0; m < MPS; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
