@@ -68,6 +68,8 @@ struct GemmArgs {
   float *partial;
   // diagnostic (MDHIP_GEMM_STAMP=1, never set in production): per block {shader cycles, 100 MHz ticks} around the whole kernel body
   unsigned long long *stamp;
+  // ragged direct-to-LDS kernels: 16 B of zeros in device memory — what a DMA lane fetches for a position outside the operand
+  const float *zero;
 };
 
 // Tile loaders for a ROWS x BK operand tile, NT threads, 16 B per thread per pass.
@@ -409,19 +411,25 @@ __global__ void __launch_bounds__(64 * WM * WN, (EPI != 0 && BM * BN <= 256 * 12
 // drains the DMA (s_waitcnt vmcnt(0)) in front of every step's ds_read (seen in the .s of the first version of this kernel).
 typedef __attribute__((address_space(3))) void md_lds_void;
 typedef __attribute__((address_space(1))) const void md_gbl_void;
-template <int ROWS, int BK, int NT>
-__device__ __forceinline__ void glds_tile_pass(const float *__restrict__ P, int64_t ks, int64_t row0, int64_t k0, float *S, int i) {
+// RAGGED (problem sizes that the tiles do not divide; operand rows a multiple of 4 so that no 16-B piece straddles the edge): a lane
+// whose four rows or whose k lie outside the operand fetches 16 B of zeros instead (the SOURCE of a DMA is per lane) — the tile
+// image is then complete, the main loop is the same, the epilogue drops the rows / columns outside C.
+template <int ROWS, int BK, int NT, bool RAGGED = false>
+__device__ __forceinline__ void glds_tile_pass(const float *__restrict__ P, int64_t ks, int64_t row0, int64_t k0, float *S, int i,
+                                               int64_t rows_total = 0, int64_t k_total = 0, const float *zero = nullptr) {
   constexpr int NW = NT / 64;
   static_assert(ROWS * BK % (256 * NW) == 0 && (ROWS & (ROWS - 1)) == 0, "whole 1-KiB pieces per wave");
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int piece = i * NW + wave;
   const int f = piece * 256 + lane * 4, k = f / ROWS, r = f % ROWS;
-  __builtin_amdgcn_global_load_lds((md_gbl_void *)(P + (row0 + r) + (k0 + k) * ks), (md_lds_void *)(S + piece * 256), 16, 0, 0);
+  const float *src = P + (row0 + r) + (k0 + k) * ks;
+  if constexpr (RAGGED) src = (row0 + r < rows_total && k0 + k < k_total) ? src : zero;
+  __builtin_amdgcn_global_load_lds((md_gbl_void *)src, (md_lds_void *)(S + piece * 256), 16, 0, 0);
 }
 
 template <int V> struct MdInt { static constexpr int value = V; };
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, bool RAGGED = false>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);
@@ -464,11 +472,11 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int64_t nk = g.K / BK;   // whole k-tiles only (the launcher checks)
+  const int64_t nk = RAGGED ? (g.K + BK - 1) / BK : g.K / BK;   // (plain form: whole k-tiles only, the launcher checks)
 #pragma unroll
-  for (int i = 0; i < PA; ++i) glds_tile_pass<BM, BK, NT>(A, g.a_ks, m0, 0, &A0[0][0], i);
+  for (int i = 0; i < PA; ++i) glds_tile_pass<BM, BK, NT, RAGGED>(A, g.a_ks, m0, 0, &A0[0][0], i, g.M, g.K, g.zero);
 #pragma unroll
-  for (int i = 0; i < PB; ++i) glds_tile_pass<BN, BK, NT>(B, g.b_ks, n0, 0, &B0[0][0], i);
+  for (int i = 0; i < PB; ++i) glds_tile_pass<BN, BK, NT, RAGGED>(B, g.b_ks, n0, 0, &B0[0][0], i, g.N, g.K, g.zero);
   __syncthreads();
 
   // fragments for TWO steps (4 k) per LDS instruction: rows 4p+h and 4p+2+h of the [k][row] image lie 2*ROWS floats apart, a
@@ -502,8 +510,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < PPS; ++q) {
           const int pi = sidx * PPS + q;
-          if (pi < PA) { glds_tile_pass<BM, BK, NT>(A, g.a_ks, m0, kn * BK, CUR ? &A0[0][0] : &A1[0][0], pi); ++n_dma; }
-          else if (pi < PA + PB) { glds_tile_pass<BN, BK, NT>(B, g.b_ks, n0, kn * BK, CUR ? &B0[0][0] : &B1[0][0], pi - PA); ++n_dma; }
+          if (pi < PA) { glds_tile_pass<BM, BK, NT, RAGGED>(A, g.a_ks, m0, kn * BK, CUR ? &A0[0][0] : &A1[0][0], pi, g.M, g.K, g.zero); ++n_dma; }
+          else if (pi < PA + PB) { glds_tile_pass<BN, BK, NT, RAGGED>(B, g.b_ks, n0, kn * BK, CUR ? &B0[0][0] : &B1[0][0], pi - PA, g.N, g.K, g.zero); ++n_dma; }
         }
 #pragma unroll
         for (int i = 0; i < WTM; ++i)
@@ -538,7 +546,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wm * (WTM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        C[row * g.c_ms + col * g.c_ns] = acc[i][j][r];
+        if (!RAGGED || (row < g.M && col < g.N)) C[row * g.c_ms + col * g.c_ns] = acc[i][j][r];
       }
     }
 }
@@ -552,18 +560,21 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
 // (0,1),(2,3)..: a different rounding sequence from the register-staged kernel (both are plain f32 fma chains; integers stay exact).
 // B is either k-contiguous too (NT: same image) or row-contiguous (NN: the [k][n] image of k_gemm_f32_tn_glds, b32 reads at
 // k = 8j + 4h + t). 16 consecutive lanes of a b128 read cover one 256-B run of a piece: no bank conflicts.
-template <int ROWS, int BK, int NT>
-__device__ __forceinline__ void glds_kc_pass(const float *__restrict__ P, int64_t rs, int64_t row0, int64_t k0, float *S, int i) {
+template <int ROWS, int BK, int NT, bool RAGGED = false>
+__device__ __forceinline__ void glds_kc_pass(const float *__restrict__ P, int64_t rs, int64_t row0, int64_t k0, float *S, int i,
+                                             int64_t rows_total = 0, int64_t k_total = 0, const float *zero = nullptr) {
   constexpr int NW = NT / 64, KH = BK / 16;
   static_assert(ROWS * BK % (256 * NW) == 0 && BK % 16 == 0, "whole 1-KiB pieces per wave");
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   // a wave takes BOTH k-halves of a 16-row block back to back (the two pieces share their 128-B lines)
   const int rb = (i / KH) * NW + wave, kh = i % KH;
   const int row = rb * 16 + (lane & 15), k = kh * 16 + (lane >> 4) * 4;
-  __builtin_amdgcn_global_load_lds((md_gbl_void *)(P + (row0 + row) * rs + k0 + k), (md_lds_void *)(S + (rb * KH + kh) * 256), 16, 0, 0);
+  const float *src = P + (row0 + row) * rs + k0 + k;
+  if constexpr (RAGGED) src = (row0 + row < rows_total && k0 + k < k_total) ? src : zero;   // (K % 4 == 0: no piece straddles the end)
+  __builtin_amdgcn_global_load_lds((md_gbl_void *)src, (md_lds_void *)(S + (rb * KH + kh) * 256), 16, 0, 0);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool B_KC, int EPI = 0>
+template <int BM, int BN, int BK, int WM, int WN, bool B_KC, int EPI = 0, bool RAGGED = false>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);
@@ -613,15 +624,15 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int64_t nk = g.K / BK;
+  const int64_t nk = RAGGED ? (g.K + BK - 1) / BK : g.K / BK;
   unsigned long long st_c = 0, st_r = 0;   // diagnostic stamps (MDHIP_GEMM_STAMP=1), as in k_gemm_f32_mfma
   if (g.stamp) { st_c = __builtin_amdgcn_s_memtime(); st_r = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll
-  for (int i = 0; i < PA; ++i) glds_kc_pass<BM, BK, NT>(A, g.a_ms, m0, 0, A0, i);
+  for (int i = 0; i < PA; ++i) glds_kc_pass<BM, BK, NT, RAGGED>(A, g.a_ms, m0, 0, A0, i, g.M, g.K, g.zero);
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
-    if constexpr (B_KC) glds_kc_pass<BN, BK, NT>(B, g.b_ns, n0, 0, B0, i);
-    else glds_tile_pass<BN, BK, NT>(B, g.b_ks, n0, 0, B0, i);
+    if constexpr (B_KC) glds_kc_pass<BN, BK, NT, RAGGED>(B, g.b_ns, n0, 0, B0, i, g.N, g.K, g.zero);
+    else glds_tile_pass<BN, BK, NT, RAGGED>(B, g.b_ks, n0, 0, B0, i, g.N, g.K, g.zero);
   }
   __syncthreads();
 
@@ -654,10 +665,10 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < PPS; ++q) {
           const int pi = sidx * PPS + q;
-          if (pi < PA) { glds_kc_pass<BM, BK, NT>(A, g.a_ms, m0, kn * BK, CUR ? A0 : A1, pi); ++n_dma; }
+          if (pi < PA) { glds_kc_pass<BM, BK, NT, RAGGED>(A, g.a_ms, m0, kn * BK, CUR ? A0 : A1, pi, g.M, g.K, g.zero); ++n_dma; }
           else if (pi < PA + PB) {
-            if constexpr (B_KC) glds_kc_pass<BN, BK, NT>(B, g.b_ns, n0, kn * BK, CUR ? B0 : B1, pi - PA);
-            else glds_tile_pass<BN, BK, NT>(B, g.b_ks, n0, kn * BK, CUR ? B0 : B1, pi - PA);
+            if constexpr (B_KC) glds_kc_pass<BN, BK, NT, RAGGED>(B, g.b_ns, n0, kn * BK, CUR ? B0 : B1, pi - PA, g.N, g.K, g.zero);
+            else glds_tile_pass<BN, BK, NT, RAGGED>(B, g.b_ks, n0, kn * BK, CUR ? B0 : B1, pi - PA, g.N, g.K, g.zero);
             ++n_dma;
           }
         }
@@ -709,7 +720,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wm * (WTM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        C[row * g.c_ms + col * g.c_ns] = acc[i][j][r];
+        if (!RAGGED || (row < g.M && col < g.N)) C[row * g.c_ms + col * g.c_ns] = acc[i][j][r];
       }
     }
 }
@@ -751,6 +762,16 @@ __global__ void __launch_bounds__(MD_BLOCK) k_gemm_splitk_sum(const float *__res
     const int64_t b = i / (M * N), r = i - b * (M * N), m = r / N, n = r - m * N;
     C[b * c_bs + m * c_ms + n * c_ns] = acc;
   }
+}
+
+// 64 B of zeros in device memory for the ragged direct-to-LDS kernels (GemmArgs::zero); allocated once, never freed
+static const float *md_zero_block() {
+  static const float *z = [] {
+    void *p = nullptr;
+    if (hipMalloc(&p, 64) != hipSuccess || hipMemset(p, 0, 64) != hipSuccess) return (const float *)nullptr;
+    return (const float *)p;
+  }();
+  return z;
 }
 
 // Launch of a main GEMM kernel: with events attached (mdhip_event_attach_next, bench.py) the dispatch itself carries the start / stop
@@ -797,6 +818,7 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
     static const int sh = [] { const char *e = getenv("MDHIP_GEMM_SUPER"); return e ? atoi(e) : 8; }();
     ga.super_h = (sh > 1 && ga.tiles_m >= sh && ga.tiles_n >= 8) ? sh : 0;
   }
+  const bool aligned = !edge;   // (on entry `edge` only says whether the operands are 16-B aligned)
   edge = edge || (ga.M % BM) || (ga.N % BN) || (ga.K % BK);
   if constexpr (EPI != 0) {  // whole aligned tiles only; the caller falls back to the plain product otherwise
     if (edge || batch != 1) return MDHIP_EVALUE;
@@ -840,7 +862,16 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
     StampDump::get().note(BM, BN, BK, (size_t)grid.x * grid.z);
   }
   if (splits == 1) {
-    if (edge) md_gemm_launch(k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, true>, grid, 64 * WM * WN, ga);
+    bool ragged_dma = false;
+    if constexpr (!A_KC && !B_KC && SCHED != 0 && BK >= 32) {
+      // ragged TN: still direct to LDS when every 16-B piece lies wholly inside or outside the operands (M, N multiples of 4)
+      const char *e = getenv("MDHIP_GEMM_GLDS");
+      ragged_dma = edge && aligned && (e ? atoi(e) != 0 : true) && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp && ga.M % 4 == 0 && ga.N % 4 == 0 &&
+                   (ga.zero = md_zero_block()) != nullptr;
+      if (ragged_dma) md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN, true>, grid, 64 * WM * WN, ga);
+    }
+    if (ragged_dma) {
+    } else if (edge) md_gemm_launch(k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, true>, grid, 64 * WM * WN, ga);
     else {
       bool glds = false;
       if constexpr (!A_KC && !B_KC && SCHED != 0 && BK >= 32) {
@@ -888,7 +919,7 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged, bool 
   double best_t = 1e300;
   for (int ci = 0; ci < 6; ++ci) {
     const Cand &c = vector_staged ? cands_tn[ci] : cands[ci];
-    const bool dma = dma_ok && c.tf_dma > 0.0 && ga.M % c.bm == 0 && ga.N % c.bn == 0 && ga.K % 32 == 0;
+    const bool dma = dma_ok && c.tf_dma > 0.0;   // (ragged sizes run the same kernels with zero-filled edges: launch_mfma checks what they need)
     const double tf = dma ? c.tf_dma : c.tf;
     if (tf <= 0.0) continue;
     const int64_t tiles = ((ga.M + c.bm - 1) / c.bm) * ((ga.N + c.bn - 1) / c.bn) * batch;
@@ -898,6 +929,9 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged, bool 
     // rate was measured that way (16 MFMAs per step and wave), and the eight-wave tile
     if (tiles <= MD_NUM_CUS && c.cfg != CFG_128x128_W8 && c.cfg != CFG_256x256x32) t /= 0.8;
     if (c.cfg == CFG_256x256x32 && tiles < MD_NUM_CUS) continue;   // (half-empty chip: never the best choice)
+    // the register-staged kernel's guarded edge variant runs ~15 % below its whole-tile rate (4000^3: 112-115 against 133-139);
+    // the direct-to-LDS kernels pay nothing for a ragged edge (zero-filled DMA lanes)
+    if (!dma && ((ga.M % c.bm) || (ga.N % c.bn) || (ga.K % 16))) t /= 0.85;
     if (t < best_t * 0.999) { best_t = t; best = c.cfg; }   // ties go to the larger tile (listed first)
   }
   return best;
@@ -906,9 +940,13 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged, bool 
 // NN / NT with whole aligned tiles: the direct-to-LDS kernel for k-contiguous operands (k_gemm_f32_kc_glds); -1 = not applicable
 template <int BM, int BN, int WM, int WN, bool B_KC, int EPI = 0, int BK = 32>
 static int launch_kc_glds(GemmArgs ga, int64_t batch, bool edge) {
-  if (edge || (ga.M % BM) || (ga.N % BN) || (ga.K % BK) || ga.a_ks != 1 || (B_KC ? ga.b_ks != 1 : ga.b_ns != 1)) return -1;
-  ga.tiles_m = (int)(ga.M / BM);
-  ga.tiles_n = (int)(ga.N / BN);
+  if (edge || ga.a_ks != 1 || (B_KC ? ga.b_ks != 1 : ga.b_ns != 1)) return -1;
+  const bool ragged = (ga.M % BM) || (ga.N % BN) || (ga.K % BK);
+  if (ragged) {   // every 16-B piece wholly inside or outside the operands: K (k-contiguous operands) and N (NN's B) multiples of 4
+    if (EPI != 0 || (ga.K % 4) || (!B_KC && (ga.N % 4)) || (ga.zero = md_zero_block()) == nullptr) return -1;
+  }
+  ga.tiles_m = (int)((ga.M + BM - 1) / BM);
+  ga.tiles_n = (int)((ga.N + BN - 1) / BN);
   static const int sh = [] { const char *e = getenv("MDHIP_GEMM_SUPER"); return e ? atoi(e) : 8; }();
   ga.super_h = (sh > 1 && ga.tiles_m >= sh && ga.tiles_n >= 8) ? sh : 0;
   dim3 grid((unsigned)(ga.tiles_m * ga.tiles_n), 1, (unsigned)batch);
@@ -916,6 +954,12 @@ static int launch_kc_glds(GemmArgs ga, int64_t batch, bool edge) {
   if (stamp && (size_t)grid.x * grid.z <= StampDump::kMax) {
     ga.stamp = StampDump::get().buffer();
     StampDump::get().note(BM, BN, BK, (size_t)grid.x * grid.z);
+  }
+  if constexpr (EPI == 0) {
+    if (ragged) {
+      md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, 0, true>, grid, 64 * WM * WN, ga);
+      return MD_LAUNCH_CHECK("matmul(f32 mfma, direct-to-LDS, ragged)");
+    }
   }
   md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, EPI>, grid, 64 * WM * WN, ga);
   return MD_LAUNCH_CHECK("matmul(f32 mfma, direct-to-LDS)");
@@ -927,7 +971,9 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
   // the register-staged kernels: A/B runs and tests)
   const char *e = getenv("MDHIP_GEMM_GLDS");
   const bool dma_ok = (e ? atoi(e) != 0 : true) && !edge && !ga.stamp && (A_KC ? ga.a_ks == 1 : ga.a_ms == 1) && (B_KC ? ga.b_ks == 1 : ga.b_ns == 1) &&
-                      (A_KC || !B_KC);   // (A row-contiguous with B k-contiguous — "TT" — has no such kernel)
+                      (A_KC || !B_KC) &&   // (A row-contiguous with B k-contiguous — "TT" — has no such kernel)
+                      // sizes the tiles do not divide: every 16-B piece must lie wholly inside or outside its operand
+                      ((A_KC || B_KC) ? ga.K % 4 == 0 : true) && (A_KC || ga.M % 4 == 0) && (B_KC || ga.N % 4 == 0);
   const int cfg = pick_cfg(ga, batch, !A_KC && !B_KC, dma_ok);
   if constexpr (A_KC) {
     if (dma_ok) {

@@ -11,11 +11,11 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from minidiff_amd import _capi, ndarray as nd  # noqa: E402
 
-CFGS = {0: "128x128x16", 1: "64x64x16", 2: "128x64x16", 3: "256x128x16", 4: "256x256x32 (TN)", 5: "128x128x32 (TN)", 6: "128x64x32 (TN)", 7: "128x128 8 waves"}
+CFGS = {-1: "auto (tile picker)", 0: "128x128x16", 1: "64x64x16", 2: "128x64x16", 3: "256x128x16", 4: "256x256x32 (TN)", 5: "128x128x32 (TN)", 6: "128x64x32 (TN)", 7: "128x128 8 waves"}
 if os.environ.get("GEMM_CFGS"):
     CFGS = {int(k): CFGS[int(k)] for k in os.environ["GEMM_CFGS"].split(",")}
 if os.environ.get("GEMM_GLDS_AB"):   # every config twice: register staging / direct-to-LDS staging (MDHIP_GEMM_GLDS is read per launch)
-    CFGS = {k + 100 * g: v + (" +glds" if g else "") for k, v in CFGS.items() for g in (0, 1)}
+    CFGS = {(99 if k == -1 else k) + 100 * g: v + (" +glds" if g else "") for k, v in CFGS.items() for g in (0, 1)}   # (99 = auto)
 
 
 def main():
@@ -36,7 +36,10 @@ def main():
         res = {}
         for rnd in range(3):
             for cfg in CFGS:
-                os.environ["MDHIP_GEMM_CFG"] = str(cfg % 100)
+                if cfg % 100 == 99 or cfg == -1:
+                    os.environ.pop("MDHIP_GEMM_CFG", None)      # the library's own choice
+                else:
+                    os.environ["MDHIP_GEMM_CFG"] = str(cfg % 100)
                 if os.environ.get("GEMM_GLDS_AB"):
                     os.environ["MDHIP_GEMM_GLDS"] = str(cfg // 100)
                 combos = (("NN", A, B), ("NT", A, Bt.T), ("TN", At.T, B)) + ((("TT", At.T, Bt.T),) if os.environ.get("GEMM_TT") else ())
@@ -57,7 +60,7 @@ def main():
         print(f"M={M} K={K} N={N}")
         for cfg, name in CFGS.items():
             print("   %-22s " % name + "  ".join("%s med %6.1f max %6.1f TF" % (t, sorted(res[(cfg, t)])[1], max(res[(cfg, t)])) for t in (("NN", "NT", "TN", "TT") if os.environ.get("GEMM_TT") else ("NN", "NT", "TN"))))
-    del os.environ["MDHIP_GEMM_CFG"]
+    os.environ.pop("MDHIP_GEMM_CFG", None)
     os.environ.pop("MDHIP_GEMM_GLDS", None)
 
 

@@ -213,7 +213,8 @@ def test_every_gemm_tile_config_exact_on_integers(lib, on_gpu, tile, glds, monke
     rng = np.random.default_rng(100 + tile)
     prev = nd.set_lazy(False)
     try:
-        for (M, K, N) in ((512, 128, 256), (300, 70, 200), (256, 2048, 128), (256, 96, 256), (256, 32, 512)):
+        for (M, K, N) in ((512, 128, 256), (300, 70, 200), (256, 2048, 128), (256, 96, 256), (256, 32, 512),
+                          (300, 72, 200), (260, 100, 132), (516, 36, 260), (131, 64, 257)):   # (ragged with 4-multiples: zero-filled DMA edges)
             A = rng.integers(-4, 5, (M, K)).astype(np.float32)
             B = rng.integers(-4, 5, (K, N)).astype(np.float32)
             ref = A.astype(np.float64) @ B
@@ -240,16 +241,16 @@ def test_every_gemm_tile_config_exact_on_integers(lib, on_gpu, tile, glds, monke
 
 
 def test_direct_to_lds_gemm_random_aligned_shapes(lib, on_gpu):
-    """Random whole-tile shapes, batches, aligned sub-views and transposed operands through the tile picker (no forced config):
+    """Random whole-tile and ragged (multiples of 4) shapes, batches, aligned sub-views and transposed operands through the tile picker (no forced config):
     integer-valued operands, so every product must EQUAL NumPy's; a float case per shape within 2e-6."""
     assert on_gpu
     from minidiff_amd import ndarray as nd
     rng = np.random.default_rng(2026)
     prev = nd.set_lazy(False)
     try:
-        for case in range(36):
-            M, N = (int(rng.choice([128, 256, 384, 512, 768, 1024])) for _ in range(2))
-            K = int(rng.choice([32, 64, 96, 160, 256, 480, 1024]))
+        for case in range(60):
+            M, N = (int(rng.choice([128, 256, 384, 512, 768, 1024, 132, 260, 500, 1000])) for _ in range(2))
+            K = int(rng.choice([32, 64, 96, 160, 256, 480, 1024, 36, 100, 420]))
             batch = int(rng.choice([0, 0, 0, 2, 3]))
             lay = str(rng.choice(["NN", "NT", "TN", "TT"]))
             lead = (batch,) if batch else ()
