@@ -197,7 +197,11 @@ def one_case(rng, big):
                 assert got.shape == exp.shape and got.dtype == exp.dtype, f"{name} {h.shape} axis={axis}: {got.shape}/{got.dtype} vs {exp.shape}/{exp.dtype}"
                 scale = np.abs(h.astype(np.float64)).sum() + 1.0 if name != "prod" else np.abs(exp).max() + 1.0
                 tol = 2e-6 if h.dtype == np.float32 else 1e-13
-                assert np.abs(got.astype(np.float64) - exp.astype(np.float64)).max() <= tol * scale * (50 if name == "prod" else 1), f"{name} {h.shape}{h.dtype} axis={axis}"
+                # a product's rounding error grows with the number of factors and depends on their order (tree here, pairwise
+                # blocks in NumPy): ~sqrt(n) ulp typically — 1e6 factors once missed a flat 50-ulp bound (seed 101 --big)
+                n_red = max(h.size // max(exp.size, 1), 1)
+                slack = 50 * max(1.0, (n_red / 4096.0) ** 0.5) if name == "prod" else 1
+                assert np.abs(got.astype(np.float64) - exp.astype(np.float64)).max() <= tol * scale * slack, f"{name} {h.shape}{h.dtype} axis={axis}"
             else:
                 close(got, exp, f"{name} {h.shape}{h.dtype} axis={axis} keep={keep}")
         elif kind == "arg":
