@@ -200,6 +200,18 @@ int mdhip_fill(const mdhip_array *out, const mdhip_array *scalar);
 /* out[i] = start + i*step (numpy.py:125 arange) */
 int mdhip_arange(const mdhip_array *out, double start, double step);
 
+/* ======================= random fills (opt-in device RNG) ================= */
+/* Counter-based stream (Philox4x32-10, csrc/md_rng.h): element i of a fill depends on (seed, offset, i) only, the CPU test
+ * double produces the same words. kind 0: uniform [0,1) (f32/f64); 1: standard normal (f32/f64); 2: integers in [a, a+b)
+ * (i32/i64; b = span <= 2^53); 3: binomial(n = a <= 256, p = b) (i32/i64). `out` C-contiguous. The caller advances `offset`
+ * (in Philox blocks of four 32-bit words) past what a call consumed: ceil(elements * words per element / 4), words per element
+ * = 1 / 2 (uniform f32 / f64), 2 / 4 (normal), 2 (integers), n (binomial).
+ * Replaces, when asked to, rand / randn / randint / binomial of numpy.py:131-136 — whose default stays host NumPy. */
+int mdhip_random_fill(int kind, uint64_t seed, uint64_t offset, double a, double b, const mdhip_array *out);
+/* out (1-D int64, contiguous) = a uniformly random permutation of 0..n-1: indices sorted by a 64-bit key each (2 words per
+ * element). numpy.py:135-136 permutation / shuffle gather with it. */
+int mdhip_random_permutation(uint64_t seed, uint64_t offset, const mdhip_array *out);
+
 /* ======================= reductions ======================================= */
 /* Reduce x over the axes whose bit is set in axis_mask. `out` has x's ndim
  * with reduced axes of extent 1 (the caller drops them for keepdims=False).

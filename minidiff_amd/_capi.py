@@ -100,6 +100,8 @@ _PROTOTYPES = {
     "mdhip_d2h": [C.c_void_p, C.c_void_p, C.c_size_t],
     "mdhip_d2d": [C.c_void_p, C.c_void_p, C.c_size_t],
     "mdhip_sync": [],
+    "mdhip_random_fill": [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, _P(ArrayDesc)],
+    "mdhip_random_permutation": [C.c_uint64, C.c_uint64, _P(ArrayDesc)],
     "mdhip_event_create": [_P(C.c_void_p)],
     "mdhip_event_record": [C.c_void_p],
     "mdhip_event_elapsed_ms": [C.c_void_p, C.c_void_p, _P(C.c_float)],

@@ -16,6 +16,7 @@
 
 
 #include "md_hip.h"
+#include "md_rng.h"
 
 extern "C" int mdhip_alloc(size_t, void **);
 extern "C" int mdhip_free(void *);
@@ -704,4 +705,38 @@ int mdhip_scatter(const mdhip_index_plan *pl, void *dst, int dtype, const mdhip_
   return md_fail(MDHIP_ETYPE, "scatter: bad dtype code %d", dtype);
 }
 
+
+// ---- random permutation of 0..n-1 (opt-in device RNG, md_rng.h): sort the indices by a 64-bit Philox key each --------------------
+// (numpy.py:135-136 permutation / shuffle: the caller gathers with the result). The stable LSD radix sort above, 8 passes.
+}  // extern "C"
+namespace {
+__global__ void __launch_bounds__(MD_BLOCK) k_perm_keys(uint64_t *__restrict__ keys, int64_t *__restrict__ ids, int64_t n, uint64_t seed, uint64_t offset) {
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gs) {
+    keys[i] = md_rng_key(seed, offset, i);
+    ids[i] = i;
+  }
+}
+}  // namespace
+extern "C" {
+int mdhip_random_permutation(uint64_t seed, uint64_t offset, const mdhip_array *out) {
+  MD_TRY(md_check_array(out, "permutation out"));
+  if (out->dtype != MDHIP_I64 || out->ndim != 1 || (out->shape[0] > 1 && out->strides[0] != 1))
+    return md_fail(MDHIP_EVALUE, "random_permutation: out must be a contiguous 1-D int64 array");
+  const int64_t n = out->shape[0];
+  if (n == 0) return MDHIP_OK;
+  void *keys = nullptr, *ids = nullptr;
+  MD_TRY(mdhip_alloc((size_t)n * 16, &keys));
+  int rc = mdhip_alloc((size_t)n * 16, &ids);
+  if (rc == MDHIP_OK) {
+    k_perm_keys<<<md_grid_for(n), MD_BLOCK, 0, md_stream()>>>((uint64_t *)keys, (int64_t *)ids, n, seed, offset);
+    int half = 0;
+    rc = radix_sort_pairs((uint64_t *)keys, (int64_t *)ids, n, 64, &half);
+    if (rc == MDHIP_OK)
+      rc = md_hip_check(hipMemcpyAsync(out->data, (int64_t *)ids + half * n, (size_t)n * 8, hipMemcpyDeviceToDevice, md_stream()), "permutation copy");
+  }
+  if (ids) mdhip_free(ids);
+  mdhip_free(keys);
+  return rc;
+}
 }  // extern "C"

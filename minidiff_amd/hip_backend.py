@@ -10,10 +10,11 @@ Two consumers:
   * :mod:`minidiff_amd.plugin` — wraps this table in a ``minidiff.backend.Backend``
     subclass so the *unmodified* reference selects it with ``--backend``.
 
-Random draws and ``.npy`` IO are produced by NumPy on the host and uploaded
-(the reference aliases ``np.random.*`` — numpy.py:131-137 — so the stream of
-numbers for a given seed must be NumPy's); no arithmetic on the path runs on
-the CPU.
+Random draws are produced by NumPy on the host and uploaded by default (the
+reference aliases ``np.random.*`` — numpy.py:131-137 — so the stream of numbers
+for a given seed must be NumPy's); ``MDHIP_DEVICE_RNG=1`` / ``ndarray.device_rng``
+switches them to a counter-based generator on the device (csrc/md_rng.h). ``.npy``
+IO goes through page-locked host blocks; no arithmetic on the path runs on the CPU.
 """
 from __future__ import annotations
 
@@ -31,13 +32,24 @@ def _host(x):
     return x
 
 
-def _upload_random(fn):
+def _host_random(fn):
     def wrapped(*args, **kwargs):
         out = fn(*[_host(a) for a in args], **{k: _host(v) for k, v in kwargs.items()})
         return nd.asarray(np.asarray(out))
 
-    wrapped.__name__ = getattr(fn, "__name__", "random")
-    return staticmethod(wrapped)
+    return wrapped
+
+
+_HOST_RANDOM = {name: _host_random(getattr(np.random, name)) for name in ("rand", "randn", "randint", "binomial", "permutation", "choice")}
+_bi_all = all
+
+
+def _is_int(v):
+    return isinstance(v, (int, np.integer)) and not isinstance(v, (bool, np.bool_))
+
+
+def _shape_of(size):
+    return (int(size),) if _is_int(size) else tuple(int(s) for s in size)
 
 
 class HipBackendTable:
@@ -137,26 +149,87 @@ class HipBackendTable:
     arange = staticmethod(nd.arange)
     stack = staticmethod(nd.stack)
 
+    # .npy IO (numpy.py:129-130): the file format is NumPy's, written / read by NumPy itself; the payload moves device <-> file
+    # through one page-locked host block (save: D2H lands in it and np.save writes from it; load: the file is memory-mapped and
+    # uploaded from the mapping) — no second host copy, no arithmetic.
     @staticmethod
     def save(file, arr, **kw):
         np.save(file, _host(arr), **kw)
 
     @staticmethod
     def load(file, **kw):
+        if isinstance(file, (str, bytes)) or hasattr(file, "__fspath__"):
+            if "mmap_mode" not in kw and not kw.get("allow_pickle", False):
+                try:
+                    mapped = np.load(file, mmap_mode="r", **kw)
+                    if isinstance(mapped, np.memmap):
+                        return nd.asarray(mapped)
+                except ValueError:      # (object arrays, .npz archives, Fortran-order quirks: the plain reader decides)
+                    pass
         return nd.asarray(np.load(file, **kw))
 
-    choice = _upload_random(np.random.choice)
-    rand = _upload_random(np.random.rand)
-    randint = _upload_random(np.random.randint)
-    randn = _upload_random(np.random.randn)
-    binomial = _upload_random(np.random.binomial)
-    permutation = _upload_random(np.random.permutation)
+    # random draws (numpy.py:131-137): NumPy on the host by default — the reference's functions ARE np.random.*, so a seed
+    # must give NumPy's numbers. With the device generator switched on (MDHIP_DEVICE_RNG=1 / ndarray.device_rng) the forms
+    # below that it covers run on the GPU instead (own stream, same distributions); everything else still goes to NumPy.
+    @staticmethod
+    def rand(*dims):
+        if nd.device_rng_enabled() and dims and _bi_all(_is_int(d) for d in dims):
+            return nd.random_uniform(tuple(int(d) for d in dims))
+        return _HOST_RANDOM["rand"](*dims)
+
+    @staticmethod
+    def randn(*dims):
+        if nd.device_rng_enabled() and dims and _bi_all(_is_int(d) for d in dims):
+            return nd.random_normal(tuple(int(d) for d in dims))
+        return _HOST_RANDOM["randn"](*dims)
+
+    @staticmethod
+    def randint(low, high=None, size=None, dtype=int):
+        if nd.device_rng_enabled() and size is not None and _is_int(low) and (high is None or _is_int(high)) and np.dtype(dtype) in (np.dtype(np.int64), np.dtype(np.int32)):
+            lo, hi = (0, low) if high is None else (low, high)
+            return nd.random_integers(lo, hi, _shape_of(size), np.dtype(dtype))
+        return _HOST_RANDOM["randint"](low, high, size, dtype)
+
+    @staticmethod
+    def binomial(n, p, size=None):
+        if nd.device_rng_enabled() and size is not None and _is_int(n) and 0 <= int(n) <= nd.RANDOM_BINOMIAL_MAX_N and isinstance(p, (int, float, np.floating)):
+            return nd.random_binomial(n, p, _shape_of(size))
+        return _HOST_RANDOM["binomial"](n, p, size)
+
+    @staticmethod
+    def permutation(x):
+        if nd.device_rng_enabled():
+            if _is_int(x):
+                return nd.random_permutation(int(x))
+            if isinstance(x, DeviceArray) and x.ndim >= 1:
+                return x[nd.random_permutation(x.shape[0])]
+        return _HOST_RANDOM["permutation"](x)
 
     @staticmethod
     def shuffle(x):
+        if nd.device_rng_enabled() and isinstance(x, DeviceArray) and x.ndim >= 1:
+            nd._copy_into(x, x[nd.random_permutation(x.shape[0])])    # (the gather is a new array: no aliasing with the write)
+            return
         host = x.get()
         np.random.shuffle(host)
         nd._copy_into(x, nd.asarray(host))
+
+    @staticmethod
+    def choice(a, size=None, replace=True, p=None):
+        if nd.device_rng_enabled() and p is None and size is not None and (_is_int(a) or (isinstance(a, DeviceArray) and a.ndim == 1)):
+            n = int(a) if _is_int(a) else a.shape[0]
+            shape = _shape_of(size)
+            count = int(np.prod(shape, dtype=np.int64))
+            if n <= 0:
+                raise ValueError("a must be a positive integer unless no samples are taken" if _is_int(a) else "'a' cannot be empty unless no samples are taken")
+            if replace:
+                idx = nd.random_integers(0, n, shape)
+            else:
+                if count > n:
+                    raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+                idx = nd.reshape(nd.random_permutation(n)[:count], shape)
+            return idx if _is_int(a) else a[idx]
+        return _HOST_RANDOM["choice"](a, size=size, replace=replace, p=p)
 
     split = staticmethod(nd.split)
 

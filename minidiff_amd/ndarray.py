@@ -2400,3 +2400,85 @@ def materialize_many(arrays):
 
 def synchronize():
     _lib().sync()
+
+
+# ---- opt-in device RNG (csrc/md_rng.h; reference aliases: backend/numpy.py:131-137) ------------------------------------------
+# Default OFF: the reference's random functions ARE np.random.*, so a given np.random.seed must give NumPy's numbers, which
+# only the host can produce (hip_backend draws there and uploads). MDHIP_DEVICE_RNG=1 / device_rng(True, seed) switches
+# rand / randn / randint / binomial / permutation / shuffle / choice to a counter-based generator on the device: same
+# distributions, its own stream (reproducible per seed, identical on the CPU test double), nothing crosses PCIe.
+class _DeviceRng:
+    enabled = os.environ.get("MDHIP_DEVICE_RNG") == "1"
+    seed = int(os.environ.get("MDHIP_DEVICE_RNG_SEED", "0")) & 0xFFFFFFFFFFFFFFFF
+    offset = 0          # Philox blocks consumed so far
+
+
+def device_rng(enable: bool = True, seed=None) -> bool:
+    """Switch the device generator on / off (returns the previous state); `seed` restarts its stream."""
+    prev = _DeviceRng.enabled
+    _DeviceRng.enabled = bool(enable)
+    if seed is not None:
+        _DeviceRng.seed, _DeviceRng.offset = int(seed) & 0xFFFFFFFFFFFFFFFF, 0
+    return prev
+
+
+def device_rng_enabled() -> bool:
+    return _DeviceRng.enabled
+
+
+def _rng_take(words: int) -> int:
+    off = _DeviceRng.offset
+    _DeviceRng.offset += (int(words) + 3) // 4
+    return off
+
+
+_RNG_UNIFORM, _RNG_NORMAL, _RNG_INTEGERS, _RNG_BINOMIAL = 0, 1, 2, 3
+
+
+def _random_fill(kind, shape, dtype, a=0.0, b=0.0, words_per_elem=1):
+    res = DeviceArray.empty(shape, dtype)
+    if res.size:
+        _lib().random_fill(kind, _DeviceRng.seed, _rng_take(res.size * words_per_elem), float(a), float(b), res.desc())
+    return res
+
+
+def random_uniform(shape, dtype=np.float64):
+    dtype = np.dtype(dtype)
+    return _random_fill(_RNG_UNIFORM, shape, dtype, words_per_elem=2 if dtype == np.float64 else 1)
+
+
+def random_normal(shape, dtype=np.float64):
+    dtype = np.dtype(dtype)
+    return _random_fill(_RNG_NORMAL, shape, dtype, words_per_elem=4 if dtype == np.float64 else 2)
+
+
+def random_integers(low, high, shape, dtype=np.int64):
+    low, high = operator.index(low), operator.index(high)
+    if high <= low:
+        raise ValueError("low >= high")
+    if high - low > (1 << 53):
+        raise ValueError("device RNG: integer ranges up to 2**53")
+    return _random_fill(_RNG_INTEGERS, shape, np.dtype(dtype), low, high - low, words_per_elem=2)
+
+
+RANDOM_BINOMIAL_MAX_N = 256
+
+
+def random_binomial(n, p, shape, dtype=np.int64):
+    n = operator.index(n)
+    if n < 0 or n > RANDOM_BINOMIAL_MAX_N:
+        raise ValueError(f"device RNG: binomial with 0 <= n <= {RANDOM_BINOMIAL_MAX_N}")
+    if not (0.0 <= float(p) <= 1.0):          # (also rejects nan)
+        raise ValueError("p < 0, p > 1 or p is NaN")
+    return _random_fill(_RNG_BINOMIAL, shape, np.dtype(dtype), n, float(p), words_per_elem=_bi.max(n, 1))
+
+
+def random_permutation(n: int):
+    """A uniformly random permutation of 0..n-1 (int64): the indices sorted by a 64-bit random key each, on the device."""
+    n = operator.index(n)
+    if n < 0:
+        raise ValueError("negative dimensions are not allowed")
+    res = DeviceArray.empty((n,), np.int64)
+    if n:
+        _lib().random_permutation(_DeviceRng.seed, _rng_take(2 * n), res.desc())
+    return res

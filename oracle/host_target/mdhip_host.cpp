@@ -12,15 +12,18 @@
 // It shares csrc/md_ops.h + md_dispatch.h with the device build, so dispatch
 // and per-element semantics are the same code; the loops below are the naive
 // sequential restatement (no tiling, no vectorisation, k-ordered accumulation).
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <numeric>
 #include <vector>
 
 #include "../../minidiff_amd/csrc/md_dispatch.h"
 #include "../../minidiff_amd/csrc/md_vm.h"
+#include "../../minidiff_amd/csrc/md_rng.h"
 
 std::string &md_err_slot() {
   static thread_local std::string s;
@@ -230,6 +233,52 @@ int mdhip_arange(const mdhip_array *out, double start, double step) {
       default: return md_fail(MDHIP_ETYPE, "arange: unsupported dtype");
     }
   }
+  return MDHIP_OK;
+}
+// opt-in device RNG: the same Philox stream as the device kernels (md_rng.h), element by element
+int mdhip_random_fill(int kind, uint64_t seed, uint64_t offset, double a, double b, const mdhip_array *out) {
+  MD_TRY(md_check_array(out, "random out"));
+  int64_t n = 1, expect = 1;
+  for (int d = out->ndim - 1; d >= 0; --d) {
+    if (out->shape[d] != 1 && out->strides[d] != expect) return md_fail(MDHIP_EVALUE, "random_fill: out must be C-contiguous");
+    expect *= out->shape[d];
+    n *= out->shape[d];
+  }
+  const bool f = out->dtype == MDHIP_F32 || out->dtype == MDHIP_F64, in = out->dtype == MDHIP_I32 || out->dtype == MDHIP_I64;
+  if (kind < 0 || kind > 3) return md_fail(MDHIP_EVALUE, "random_fill: unknown kind %d", kind);
+  if ((kind <= MD_RNG_NORMAL) ? !f : !in) return md_fail(MDHIP_ETYPE, "random_fill: kind %d cannot fill %s", kind, md_dtype_name(out->dtype));
+  if (kind == MD_RNG_INTEGERS && (!(b >= 1.0) || b > 9007199254740992.0)) return md_fail(MDHIP_EVALUE, "random_fill: integers need 1 <= high - low <= 2^53");
+  if (kind == MD_RNG_BINOMIAL && (!(a >= 0.0) || a > (double)MD_RNG_BINOMIAL_MAX_N || !(b >= 0.0 && b <= 1.0)))
+    return md_fail(MDHIP_EVALUE, "random_fill: binomial needs 0 <= n <= %d and 0 <= p <= 1", MD_RNG_BINOMIAL_MAX_N);
+  for (int64_t i = 0; i < n; ++i) {
+    switch (kind) {
+      case MD_RNG_UNIFORM:
+        if (out->dtype == MDHIP_F32) ((float *)out->data)[i] = md_rng_uniform<float>(seed, offset, i);
+        else ((double *)out->data)[i] = md_rng_uniform<double>(seed, offset, i);
+        break;
+      case MD_RNG_NORMAL:
+        if (out->dtype == MDHIP_F32) ((float *)out->data)[i] = md_rng_normal<float>(seed, offset, i);
+        else ((double *)out->data)[i] = md_rng_normal<double>(seed, offset, i);
+        break;
+      default: {
+        const int64_t v = kind == MD_RNG_INTEGERS ? md_rng_integer(seed, offset, i, (int64_t)a, (uint64_t)b) : md_rng_binomial(seed, offset, i, (int64_t)a, b);
+        if (out->dtype == MDHIP_I64) ((int64_t *)out->data)[i] = v;
+        else ((int32_t *)out->data)[i] = (int32_t)v;
+      }
+    }
+  }
+  return MDHIP_OK;
+}
+int mdhip_random_permutation(uint64_t seed, uint64_t offset, const mdhip_array *out) {
+  MD_TRY(md_check_array(out, "permutation out"));
+  if (out->dtype != MDHIP_I64 || out->ndim != 1 || (out->shape[0] > 1 && out->strides[0] != 1))
+    return md_fail(MDHIP_EVALUE, "random_permutation: out must be a contiguous 1-D int64 array");
+  const int64_t n = out->shape[0];
+  std::vector<uint64_t> keys((size_t)n);
+  for (int64_t i = 0; i < n; ++i) keys[(size_t)i] = md_rng_key(seed, offset, i);
+  int64_t *ids = (int64_t *)out->data;
+  std::iota(ids, ids + n, (int64_t)0);
+  std::stable_sort(ids, ids + n, [&](int64_t x, int64_t y) { return keys[(size_t)x] < keys[(size_t)y]; });   // (stable, like the device's LSD radix sort)
   return MDHIP_OK;
 }
 int mdhip_reduce(int op, const mdhip_array *x, const mdhip_array *out, uint32_t mask) {
