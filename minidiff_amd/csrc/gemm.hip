@@ -436,10 +436,10 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
   constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NSTEP = BK / 2;
   constexpr int DMA_STEPS = NSTEP / 2;                        // the next tile's DMA pieces are issued within the first half of the k-tile
   constexpr int PPS = (PA + PB + DMA_STEPS - 1) / DMA_STEPS;  // (4 / 2 steps instead of 8: no difference for this kernel, r2_gemm_glds_ab.log)
-  __shared__ float A0[BK][BM];
-  __shared__ float A1[BK][BM];
-  __shared__ float B0[BK][BN];
-  __shared__ float B1[BK][BN];
+  __shared__ __attribute__((aligned(16))) float A0[BK][BM];   // (DMA destinations: 16-B pieces)
+  __shared__ __attribute__((aligned(16))) float A1[BK][BM];
+  __shared__ __attribute__((aligned(16))) float B0[BK][BN];
+  __shared__ __attribute__((aligned(16))) float B1[BK][BN];
 
   const int nblk = g.tiles_m * g.tiles_n;
   int bid = blockIdx.x;
