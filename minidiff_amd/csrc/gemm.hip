@@ -1282,7 +1282,10 @@ template <int BM, int BN, int WM = 2, int WN = 2, bool DMA = false> static int l
   float *out = ga.partial;  // (the caller parked the 0-d result pointer here)
   ga.partial = (float *)partial;
   int rc;
-  if constexpr (DMA) rc = launch_kc_glds<BM, BN, WM, WN, false, 1>(ga, 1, false);   // (the caller checked whole tiles and alignment)
+  if constexpr (DMA) {
+    rc = launch_kc_glds<BM, BN, WM, WN, false, 1>(ga, 1, false);   // (the caller checked whole tiles and alignment)
+    if (rc < 0) rc = md_fail(MDHIP_EVALUE, "matmul_bias_relu_sum: shape not covered by the fused kernel");
+  }
   else rc = launch_cfg<BM, BN, 16, WM, WN, true, false, BM == 64 ? 0 : 1, 1>(ga, 1, false);
   if (rc == MDHIP_OK) {
     k_gemm_epi_finish<<<1, MD_BLOCK, 0, md_stream()>>>((const float *)partial, tiles, out);
