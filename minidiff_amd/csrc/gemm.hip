@@ -427,6 +427,32 @@ __device__ __forceinline__ void glds_tile_pass(const float *__restrict__ P, int6
   __builtin_amdgcn_global_load_lds((md_gbl_void *)src, (md_lds_void *)(S + piece * 256), 16, 0, 0);
 }
 
+// The same piece with the address split into a WAVE-UNIFORM base (scalar registers; advanced per pass and per k-tile by scalar
+// arithmetic) and a loop-invariant 32-bit per-lane byte offset: the DMA then takes its address as `v_offset, s[base]` and costs no
+// vector ALU work. With the full 64-bit address per lane (above) the compiler re-derived it for every piece — a 32-bit multiply, a
+// 64-bit multiply-add and two 64-bit shift-adds, ~45 cycles of VALU per DMA, which a lone wave per SIMD cannot hide behind a 64-cycle
+// MFMA: ablation (profiles/r2_gemm_glds_ab.log, fifth part) priced the DMAs at 3.9 % of the 256x256 kernel and 8.7 % of the eight-wave
+// 128x128 one. Whole-tile kernels only (the ragged variants select between two addresses per lane).
+template <int ROWS> __device__ __forceinline__ uint32_t glds_tile_lane_off(int64_t ks) {
+  const int lane = threadIdx.x & 63;
+  constexpr int LPR = ROWS / 4 > 64 ? 64 : ROWS / 4;   // lanes per k-row
+  return (uint32_t)(((int64_t)(lane / LPR) * ks + (lane % LPR) * 4) * 4);
+}
+// `wbase` = the wave's first piece of tile 0 (uniform pointer: P + row0 + wave * KPP * ks), `step` = floats between a wave's consecutive
+// pieces (NW * KPP * ks), `koff` = floats from tile 0 to this k-tile (k0 * ks): adds only, in scalar registers.
+template <int ROWS, int BK, int NT>
+__device__ __forceinline__ void glds_tile_pass_u(const float *wbase, int64_t step, int64_t koff, float *S, int i, uint32_t lane_off) {
+  constexpr int NW = NT / 64;
+  static_assert(ROWS <= 256, "a piece covers whole k-rows");
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const char *ub = reinterpret_cast<const char *>(wbase + koff + (int64_t)i * step);
+  // keeps the 32 -> 64-bit extension of the lane offset next to the DMA (address mode `v_offset, s[base]`; hoisted out of the loop it
+  // arrives as a 64-bit register pair and the DMA takes the slow per-lane 64-bit form): an empty, NON-volatile statement that "depends" on
+  // the k-tile offset, so it can neither leave the loop nor pin the instruction order
+  asm("" : "+v"(lane_off) : "s"((int)koff));
+  __builtin_amdgcn_global_load_lds((md_gbl_void *)(ub + lane_off), (md_lds_void *)(S + (i * NW + wave) * 256), 16, 0, 0);
+}
+
 template <int V> struct MdInt { static constexpr int value = V; };
 
 template <int BM, int BN, int BK, int WM, int WN, bool RAGGED = false>
@@ -477,6 +503,10 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
   for (int i = 0; i < PA; ++i) glds_tile_pass<BM, BK, NT, RAGGED>(A, g.a_ks, m0, 0, &A0[0][0], i, g.M, g.K, g.zero);
 #pragma unroll
   for (int i = 0; i < PB; ++i) glds_tile_pass<BN, BK, NT, RAGGED>(B, g.b_ks, n0, 0, &B0[0][0], i, g.N, g.K, g.zero);
+  const uint32_t la = glds_tile_lane_off<BM>(g.a_ks), lb = glds_tile_lane_off<BN>(g.b_ks);   // per-lane parts of the DMA addresses (loop-invariant)
+  const int uw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float *wa = A + m0 + (int64_t)uw * (256 / BM) * g.a_ks, *wb = B + n0 + (int64_t)uw * (256 / BN) * g.b_ks;   // uniform parts
+  const int64_t sa = (int64_t)(NT / 64) * (256 / BM) * g.a_ks, sb = (int64_t)(NT / 64) * (256 / BN) * g.b_ks;
   __syncthreads();
 
   // fragments for TWO steps (4 k) per LDS instruction: rows 4p+h and 4p+2+h of the [k][row] image lie 2*ROWS floats apart, a
@@ -510,8 +540,15 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < PPS; ++q) {
           const int pi = sidx * PPS + q;
-          if (pi < PA) { glds_tile_pass<BM, BK, NT, RAGGED>(A, g.a_ks, m0, kn * BK, CUR ? &A0[0][0] : &A1[0][0], pi, g.M, g.K, g.zero); ++n_dma; }
-          else if (pi < PA + PB) { glds_tile_pass<BN, BK, NT, RAGGED>(B, g.b_ks, n0, kn * BK, CUR ? &B0[0][0] : &B1[0][0], pi - PA, g.N, g.K, g.zero); ++n_dma; }
+          if (pi < PA) {
+            if constexpr (RAGGED) glds_tile_pass<BM, BK, NT, true>(A, g.a_ks, m0, kn * BK, CUR ? &A0[0][0] : &A1[0][0], pi, g.M, g.K, g.zero);
+            else glds_tile_pass_u<BM, BK, NT>(wa, sa, kn * BK * g.a_ks, CUR ? &A0[0][0] : &A1[0][0], pi, la);
+            ++n_dma;
+          } else if (pi < PA + PB) {
+            if constexpr (RAGGED) glds_tile_pass<BN, BK, NT, true>(B, g.b_ks, n0, kn * BK, CUR ? &B0[0][0] : &B1[0][0], pi - PA, g.N, g.K, g.zero);
+            else glds_tile_pass_u<BN, BK, NT>(wb, sb, kn * BK * g.b_ks, CUR ? &B0[0][0] : &B1[0][0], pi - PA, lb);
+            ++n_dma;
+          }
         }
 #pragma unroll
         for (int i = 0; i < WTM; ++i)
@@ -574,6 +611,21 @@ __device__ __forceinline__ void glds_kc_pass(const float *__restrict__ P, int64_
   __builtin_amdgcn_global_load_lds((md_gbl_void *)src, (md_lds_void *)(S + (rb * KH + kh) * 256), 16, 0, 0);
 }
 
+__device__ __forceinline__ uint32_t glds_kc_lane_off(int64_t rs) {
+  const int lane = threadIdx.x & 63;
+  return (uint32_t)(((int64_t)(lane & 15) * rs + (lane >> 4) * 4) * 4);
+}
+// `wbase` = P + (row0 + wave * 16) * rs (uniform), `step` = NW * 16 * rs floats between a wave's 16-row blocks, `k0` = first k of the tile
+template <int ROWS, int BK, int NT>
+__device__ __forceinline__ void glds_kc_pass_u(const float *wbase, int64_t step, int64_t k0, float *S, int i, uint32_t lane_off) {
+  constexpr int NW = NT / 64, KH = BK / 16;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rb = (i / KH) * NW + wave, kh = i % KH;
+  const char *ub = reinterpret_cast<const char *>(wbase + (int64_t)(i / KH) * step + k0 + kh * 16);
+  asm("" : "+v"(lane_off) : "s"((int)k0));   // (as in glds_tile_pass_u)
+  __builtin_amdgcn_global_load_lds((md_gbl_void *)(ub + lane_off), (md_lds_void *)(S + (rb * KH + kh) * 256), 16, 0, 0);
+}
+
 template <int BM, int BN, int BK, int WM, int WN, bool B_KC, int EPI = 0, bool RAGGED = false>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
   constexpr int NT = 64 * WM * WN;
@@ -634,6 +686,11 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
     if constexpr (B_KC) glds_kc_pass<BN, BK, NT, RAGGED>(B, g.b_ns, n0, 0, B0, i, g.N, g.K, g.zero);
     else glds_tile_pass<BN, BK, NT, RAGGED>(B, g.b_ks, n0, 0, B0, i, g.N, g.K, g.zero);
   }
+  const uint32_t la = glds_kc_lane_off(g.a_ms), lb = B_KC ? glds_kc_lane_off(g.b_ns) : glds_tile_lane_off<BN>(g.b_ks);   // (loop-invariant lane parts of the DMA addresses)
+  const int uw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float *wa = A + (m0 + (int64_t)uw * 16) * g.a_ms;   // uniform parts: adds only inside the loop
+  const float *wb = B_KC ? B + (n0 + (int64_t)uw * 16) * g.b_ns : B + n0 + (int64_t)uw * (256 / BN) * g.b_ks;
+  const int64_t sa = (int64_t)(NT / 64) * 16 * g.a_ms, sb = B_KC ? (int64_t)(NT / 64) * 16 * g.b_ns : (int64_t)(NT / 64) * (256 / BN) * g.b_ks;
   __syncthreads();
 
   f32x4 fa[2][WTM], fb[2][WTN];
@@ -657,7 +714,9 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int c = j & 1;
+#ifndef MD_ABL_NOREAD
       if (j + 1 < NP) MD_KC_READ(CUR, j + 1, c ^ 1)
+#endif
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int sidx = j * 4 + t;
@@ -665,12 +724,22 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < PPS; ++q) {
           const int pi = sidx * PPS + q;
-          if (pi < PA) { glds_kc_pass<BM, BK, NT, RAGGED>(A, g.a_ms, m0, kn * BK, CUR ? A0 : A1, pi, g.M, g.K, g.zero); ++n_dma; }
-          else if (pi < PA + PB) {
-            if constexpr (B_KC) glds_kc_pass<BN, BK, NT, RAGGED>(B, g.b_ns, n0, kn * BK, CUR ? B0 : B1, pi - PA, g.N, g.K, g.zero);
-            else glds_tile_pass<BN, BK, NT, RAGGED>(B, g.b_ks, n0, kn * BK, CUR ? B0 : B1, pi - PA, g.N, g.K, g.zero);
+#ifndef MD_ABL_NODMA
+          if (pi < PA) {
+            if constexpr (RAGGED) glds_kc_pass<BM, BK, NT, true>(A, g.a_ms, m0, kn * BK, CUR ? A0 : A1, pi, g.M, g.K, g.zero);
+            else glds_kc_pass_u<BM, BK, NT>(wa, sa, kn * BK, CUR ? A0 : A1, pi, la);
+            ++n_dma;
+          } else if (pi < PA + PB) {
+            if constexpr (RAGGED) {
+              if constexpr (B_KC) glds_kc_pass<BN, BK, NT, true>(B, g.b_ns, n0, kn * BK, CUR ? B0 : B1, pi - PA, g.N, g.K, g.zero);
+              else glds_tile_pass<BN, BK, NT, true>(B, g.b_ks, n0, kn * BK, CUR ? B0 : B1, pi - PA, g.N, g.K, g.zero);
+            } else {
+              if constexpr (B_KC) glds_kc_pass_u<BN, BK, NT>(wb, sb, kn * BK, CUR ? B0 : B1, pi - PA, lb);
+              else glds_tile_pass_u<BN, BK, NT>(wb, sb, kn * BK * g.b_ks, CUR ? B0 : B1, pi - PA, lb);
+            }
             ++n_dma;
           }
+#endif
         }
 #pragma unroll
         for (int i = 0; i < WTM; ++i)
@@ -691,8 +760,12 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
         }
       }
     }
+#ifndef MD_ABL_NOBAR
     __syncthreads();
+#endif
+#ifndef MD_ABL_NOREAD
     MD_KC_READ(CUR ^ 1, 0, 0)
+#endif
   };
   int64_t kt = 0;
   for (; kt + 1 < nk; kt += 2) {
