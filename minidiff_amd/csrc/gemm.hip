@@ -460,8 +460,10 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);
   constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NSTEP = BK / 2;
-  constexpr int DMA_STEPS = NSTEP / 2;                        // the next tile's DMA pieces are issued within the first half of the k-tile
-  constexpr int PPS = (PA + PB + DMA_STEPS - 1) / DMA_STEPS;  // (4 / 2 steps instead of 8: no difference for this kernel, r2_gemm_glds_ab.log)
+  // the next tile's DMA pieces go out within the first two steps of the k-tile (with the scalar-base addressing a DMA costs next to
+  // nothing to issue; the eight-wave tile gained 7 % at 2048^3 over spreading them, the 256x256 tile is indifferent)
+  constexpr int DMA_STEPS = 2;
+  constexpr int PPS = (PA + PB + DMA_STEPS - 1) / DMA_STEPS;
   __shared__ __attribute__((aligned(16))) float A0[BK][BM];   // (DMA destinations: 16-B pieces)
   __shared__ __attribute__((aligned(16))) float A1[BK][BM];
   __shared__ __attribute__((aligned(16))) float B0[BK][BN];
@@ -633,7 +635,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
   constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NSTEP = BK / 2, NP = BK / 8, KH = BK / 16;
   // the next tile's DMA pieces go out within the first DMA_STEPS steps of the k-tile (16 steps at BK 32); same-box A/B at 4096^3 NT,
   // r2_gemm_glds_ab.log: 16 steps 138.9 | 8: 144.6 | 4: 146.0 | 3: 145.5 | 2: 143.8 | 1: 140.4 TFLOP/s
-  constexpr int DMA_STEPS = 4;
+  constexpr int DMA_STEPS = 4;   // (re-checked after the scalar-base addressing: 2 -> NT 146.7, 8 -> 147.9, 4 -> 149.2)
   constexpr int PPS = (PA + PB + DMA_STEPS - 1) / DMA_STEPS;
   static_assert(NP % 2 == 0, "an even number of k-pairs per tile (fragment double buffer)");
   __shared__ __attribute__((aligned(16))) float A0[BM * BK];
@@ -984,10 +986,10 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged, bool 
   // take whole tiles and 32-deep k-tiles only; their rates apply to the candidates that divide the problem.
   if (((ga.M + 63) / 64) * ((ga.N + 63) / 64) * batch < MD_NUM_CUS && ga.K >= 1024) return CFG_64x64x16;  // split-K candidates
   struct Cand { int cfg, bm, bn; double tf, tf_dma; };   // tf_dma = 0: no direct-to-LDS form of this tile
-  static const Cand cands[] = {{CFG_256x256x32, 256, 256, 0.0, 143.0}, {CFG_256x128x16, 256, 128, 139.0, 0.0}, {CFG_128x128x16, 128, 128, 133.0, 137.0},
-                               {CFG_128x128_W8, 128, 128, 133.0, 137.5}, {CFG_128x64x16, 128, 64, 126.0, 0.0}, {CFG_64x64x16, 64, 64, 120.0, 0.0}};
-  static const Cand cands_tn[] = {{CFG_256x256x32, 256, 256, 140.0, 141.5}, {CFG_256x128x16, 256, 128, 138.0, 0.0}, {CFG_128x128x32, 128, 128, 132.0, 133.5},
-                                  {CFG_128x128_W8, 128, 128, 134.0, 136.0}, {CFG_128x64x32, 128, 64, 126.7, 128.0}, {CFG_64x64x16, 64, 64, 120.0, 0.0}};
+  static const Cand cands[] = {{CFG_256x256x32, 256, 256, 0.0, 149.0}, {CFG_256x128x16, 256, 128, 139.0, 0.0}, {CFG_128x128x16, 128, 128, 133.0, 143.0},
+                               {CFG_128x128_W8, 128, 128, 133.0, 143.5}, {CFG_128x64x16, 128, 64, 126.0, 0.0}, {CFG_64x64x16, 64, 64, 120.0, 0.0}};
+  static const Cand cands_tn[] = {{CFG_256x256x32, 256, 256, 140.0, 150.0}, {CFG_256x128x16, 256, 128, 138.0, 0.0}, {CFG_128x128x32, 128, 128, 132.0, 146.0},
+                                  {CFG_128x128_W8, 128, 128, 134.0, 146.0}, {CFG_128x64x32, 128, 64, 126.7, 138.0}, {CFG_64x64x16, 64, 64, 120.0, 0.0}};
   int best = CFG_64x64x16;
   double best_t = 1e300;
   for (int ci = 0; ci < 6; ++ci) {
@@ -1000,7 +1002,8 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged, bool 
     double t = rounds * c.bm * c.bn / tf;
     // a lone four-wave block per CU (one wave per SIMD) cannot keep the matrix pipe fed — except the 256x256 tile, whose
     // rate was measured that way (16 MFMAs per step and wave), and the eight-wave tile
-    if (tiles <= MD_NUM_CUS && c.cfg != CFG_128x128_W8 && c.cfg != CFG_256x256x32) t /= 0.8;
+    // (and the four-wave 128x128x32 direct-to-LDS tile of the TN layout: 127 against 119 TFLOP/s for the eight-wave one at 2048^3)
+    if (tiles <= MD_NUM_CUS && c.cfg != CFG_128x128_W8 && c.cfg != CFG_256x256x32 && !(vector_staged && dma && c.cfg == CFG_128x128x32)) t /= 0.8;
     if (c.cfg == CFG_256x256x32 && tiles < MD_NUM_CUS) continue;   // (half-empty chip: never the best choice)
     // the register-staged kernel's guarded edge variant runs ~15 % below its whole-tile rate (4000^3: 112-115 against 133-139);
     // the direct-to-LDS kernels pay nothing for a ragged edge (zero-filled DMA lanes)
@@ -1078,7 +1081,7 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
     // (128x128) or pay for twice the operand traffic (two 128x64 blocks): 2048^3 109-114 -> 118-123 TFLOP/s,
     // 1024x4096x4096 114-118 -> 122-126 (profiles/r2_gemm_small_grid_ab.log)
     case CFG_128x128_W8:
-      if constexpr (!A_KC && !B_KC) return launch_cfg<128, 128, 32, 4, 2, A_KC, B_KC, 1>(ga, batch, edge);
+      if constexpr (!A_KC && !B_KC) return launch_cfg<128, 128, 32, 2, 4, A_KC, B_KC, 1>(ga, batch, edge);
       else return launch_cfg<128, 128, 16, 2, 4, A_KC, B_KC, 1>(ga, batch, edge);
     default: return launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
   }
