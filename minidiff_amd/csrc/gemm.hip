@@ -26,8 +26,9 @@
 //   output tiles (per-XCD L2 locality on the shared A row panel).
 // Aligned operands whose tiles divide the problem (every BASELINE shape) run the DIRECT-TO-LDS kernels further down
 // (k_gemm_f32_kc_glds for NN / NT, k_gemm_f32_tn_glds for TN: global_load_lds_dwordx4, no staging registers, no ds_write;
-// 256x256x32 tiles, or eight waves on one 128x128x32 tile for grids of one tile per CU): 143-146 TFLOP/s at 4096^3 against
-// 139.5 for the register-staged kernel described above, which keeps the ragged / unaligned / 16-deep / split-K cases.
+// 256x256x32 tiles, or eight waves on one 128x128x32 tile for grids of one tile per CU; DMA addresses as scalar base + 32-bit
+// lane offset): 150-152 TFLOP/s at 4096^3 against 139.5 for the register-staged kernel described above, which keeps the
+// unaligned / 16-deep / split-K cases (ragged sizes with 4-multiples run RAGGED variants of the direct-to-LDS kernels).
 // ragged or unaligned shapes: guarded edge variant of the same kernel; few tiles and a long k:
 // split-K with a deterministic split-order sum. f64: the same scheme on v_mfma_f64_16x16x4_f64
 // (k_gemm_f64_mfma). Integers / tiny problems: a plain LDS-tiled kernel.
