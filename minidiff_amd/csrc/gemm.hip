@@ -942,7 +942,7 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
     if constexpr (!A_KC && !B_KC && SCHED != 0 && BK >= 32) {
       // ragged TN: still direct to LDS when every 16-B piece lies wholly inside or outside the operands (M, N multiples of 4)
       const char *e = getenv("MDHIP_GEMM_GLDS");
-      ragged_dma = edge && aligned && (e ? atoi(e) != 0 : true) && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp && ga.M % 4 == 0 && ga.N % 4 == 0 &&
+      ragged_dma = edge && aligned && (e ? atoi(e) != 0 : true) && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp && ga.M % 4 == 0 && ga.N % 4 == 0 && ga.a_ks > 0 && ga.b_ks > 0 &&
                    (ga.zero = md_zero_block()) != nullptr;
       if (ragged_dma) md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN, true>, grid, 64 * WM * WN, ga);
     }
@@ -956,7 +956,7 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
         // 4096^3 140.1 -> 141.9 TFLOP/s, the 8-wave 128x128x32 at 2048^3 119.0 -> 127.8; the 16-deep 256x128 tile LOSES
         // (135.7 -> 130.8: its k-tile is too short for a one-tile-ahead DMA) and keeps its registers.
         const char *e = getenv("MDHIP_GEMM_GLDS");
-        glds = (e ? atoi(e) != 0 : true) && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp;
+        glds = (e ? atoi(e) != 0 : true) && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp && ga.a_ks > 0 && ga.b_ks > 0 && ga.a_ks < (1ll << 26) && ga.b_ks < (1ll << 26);   // (32-bit lane offsets)
         if (glds) md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN>, grid, 64 * WM * WN, ga);
       }
       if (!glds) md_gemm_launch(k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, false, false, SCHED>, grid, 64 * WM * WN, ga);
@@ -1018,6 +1018,8 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged, bool 
 template <int BM, int BN, int WM, int WN, bool B_KC, int EPI = 0, int BK = 32>
 static int launch_kc_glds(GemmArgs ga, int64_t batch, bool edge) {
   if (edge || ga.a_ks != 1 || (B_KC ? ga.b_ks != 1 : ga.b_ns != 1)) return -1;
+  // (the per-lane part of a DMA address is a 32-bit byte offset of up to 15 rows / 3 k-rows: strides below 2^26 elements)
+  if (ga.a_ms >= (1ll << 26) || (B_KC ? ga.b_ns : ga.b_ks) >= (1ll << 26) || ga.a_ms < 0 || ga.b_ns < 0 || ga.b_ks < 0) return -1;
   const bool ragged = (ga.M % BM) || (ga.N % BN) || (ga.K % BK);
   if (ragged) {   // every 16-B piece wholly inside or outside the operands: K (k-contiguous operands) and N (NN's B) multiples of 4
     if (EPI != 0 || (ga.K % 4) || (!B_KC && (ga.N % 4)) || (ga.zero = md_zero_block()) == nullptr) return -1;
