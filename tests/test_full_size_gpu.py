@@ -271,3 +271,29 @@ def test_direct_to_lds_gemm_random_aligned_shapes(lib, on_gpu):
             assert _rel(nd.matmul(nd.asarray(fa), nd.asarray(fb)).get(), ref) < 2e-6, (case, M, K, N)
     finally:
         nd.set_lazy(prev)
+
+
+def test_gemm_whole_tile_shapes_with_unusual_strides(lib, on_gpu):
+    """Whole-tile shapes whose operands are flipped (negative strides), broadcast (stride 0) or every-other-row views: the
+    direct-to-LDS launchers must either take them correctly or leave them to the register-staged kernel — exact on integers."""
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    rng = np.random.default_rng(77)
+    M = K = N = 256
+    A = rng.integers(-3, 4, (2 * M, K)).astype(np.float32)
+    B = rng.integers(-3, 4, (K, 2 * N)).astype(np.float32)
+    dA, dB = nd.asarray(A), nd.asarray(B)
+    prev = nd.set_lazy(False)
+    try:
+        cases = [
+            (dA[:M], dB[:, :N], A[:M], B[:, :N]),                                  # plain sub-views
+            (nd.flip(dA[:M], 0), dB[:, :N], A[:M][::-1], B[:, :N]),                # negative row stride on A
+            (dA[:M], nd.flip(dB[:, :N], 1), A[:M], B[:, :N][:, ::-1]),             # negative column stride on B
+            (dA[::2], dB[:, ::2], A[::2], B[:, ::2]),                              # every other row / column
+            (nd.broadcast_to(dA[:1], (M, K)), dB[:, :N], np.broadcast_to(A[:1], (M, K)), B[:, :N]),   # stride-0 rows
+            (nd.flip(dA[:M], 0).T, nd.flip(dA[:M], 1), A[:M][::-1].T, A[:M][:, ::-1]),                # TN with flipped operands
+        ]
+        for i, (a, b, ha, hb) in enumerate(cases):
+            assert np.array_equal(nd.matmul(a, b).get(), ha.astype(np.float64) @ hb.astype(np.float64)), i
+    finally:
+        nd.set_lazy(prev)
