@@ -636,8 +636,9 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
   constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NSTEP = BK / 2, NP = BK / 8, KH = BK / 16;
   // the next tile's DMA pieces go out within the first DMA_STEPS steps of the k-tile (16 steps at BK 32); same-box A/B at 4096^3 NT,
   // r2_gemm_glds_ab.log: 16 steps 138.9 | 8: 144.6 | 4: 146.0 | 3: 145.5 | 2: 143.8 | 1: 140.4 TFLOP/s
-  constexpr int DMA_STEPS = 4;   // (re-checked after the scalar-base addressing: 2 -> NT 146.7, 8 -> 147.9, 4 -> 149.2)
-  constexpr int PPS = (PA + PB + DMA_STEPS - 1) / DMA_STEPS;
+  constexpr int DMA_STEPS = 4;   // (re-checked after the scalar-base addressing: 2 -> NT 146.7, 8 -> 147.9, 4 -> 149.2; all of the
+                                 //  eight-wave tile's four pieces behind ONE step: NN 124 -> 114, NT 121 -> 99 at 2048^3)
+  constexpr int PPS = (PA + PB + DMA_STEPS - 1) / DMA_STEPS;   // DMA pieces per step
   static_assert(NP % 2 == 0, "an even number of k-pairs per tile (fragment double buffer)");
   __shared__ __attribute__((aligned(16))) float A0[BM * BK];
   __shared__ __attribute__((aligned(16))) float A1[BM * BK];
