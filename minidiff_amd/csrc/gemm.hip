@@ -1059,7 +1059,7 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
     if (dma_ok) {
       int rc = -1;
       if (cfg == CFG_256x256x32) rc = launch_kc_glds<256, 256, 2, 2, B_KC>(ga, batch, edge);
-      else if (cfg == CFG_128x128_W8) rc = launch_kc_glds<128, 128, 2, 4, B_KC>(ga, batch, edge);   // (64-deep k-tiles: no gain, r2_gemm_glds_ab.log)
+      else if (cfg == CFG_128x128_W8) rc = launch_kc_glds<128, 128, 2, 4, B_KC>(ga, batch, edge);   // (64-deep k-tiles: no gain, before and after the addressing change)
       else if (cfg == CFG_128x128x32 || cfg == CFG_128x128x16) rc = launch_kc_glds<128, 128, 2, 2, B_KC>(ga, batch, edge);
       if (rc >= 0) return rc;
     }
