@@ -442,7 +442,7 @@ template <int ROWS> __device__ __forceinline__ uint32_t glds_tile_lane_off(int64
 // `wbase` = the wave's first piece of tile 0 (uniform pointer: P + row0 + wave * KPP * ks), `step` = floats between a wave's consecutive
 // pieces (NW * KPP * ks), `koff` = floats from tile 0 to this k-tile (k0 * ks): adds only, in scalar registers.
 template <int ROWS, int BK, int NT>
-__device__ __forceinline__ void glds_tile_pass_u(const float *wbase, int64_t step, int64_t koff, float *S, int i, uint32_t lane_off) {
+__device__ __forceinline__ void glds_tile_pass_u(const float *wbase, int64_t step, int64_t koff, float *S, int i, uint32_t lane_off, bool pred = true) {
   constexpr int NW = NT / 64;
   static_assert(ROWS <= 256, "a piece covers whole k-rows");
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -451,16 +451,20 @@ __device__ __forceinline__ void glds_tile_pass_u(const float *wbase, int64_t ste
   // arrives as a 64-bit register pair and the DMA takes the slow per-lane 64-bit form): an empty, NON-volatile statement that "depends" on
   // the k-tile offset, so it can neither leave the loop nor pin the instruction order
   asm("" : "+v"(lane_off) : "s"((int)koff));
-  __builtin_amdgcn_global_load_lds((md_gbl_void *)(ub + lane_off), (md_lds_void *)(S + (i * NW + wave) * 256), 16, 0, 0);
+  // `pred` (rows-only ragged kernels): a lane whose four rows lie outside the operand fetches nothing — its LDS slot keeps whatever an
+  // earlier tile left there, which only reaches outputs outside C (row m of A feeds row m of C alone, column n of B column n alone)
+  if (pred) __builtin_amdgcn_global_load_lds((md_gbl_void *)(ub + lane_off), (md_lds_void *)(S + (i * NW + wave) * 256), 16, 0, 0);
 }
 
 template <int V> struct MdInt { static constexpr int value = V; };
 
-template <int BM, int BN, int BK, int WM, int WN, bool RAGGED = false>
+// RAGGED: 0 whole tiles | 1 any ragged size (zero-filled lanes, 64-bit lane addresses) | 2 ragged M / N with K % BK == 0 (predicated lanes,
+// scalar-base addresses: the fast form)
+template <int BM, int BN, int BK, int WM, int WN, int RAGGED = 0>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);
-  constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NSTEP = BK / 2;
+  constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT);
   // the next tile's DMA pieces go out within the first two steps of the k-tile (with the scalar-base addressing a DMA costs next to
   // nothing to issue; the eight-wave tile gained 7 % at 2048^3 over spreading them, the 256x256 tile is indifferent)
   constexpr int DMA_STEPS = 2;
@@ -501,15 +505,21 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int64_t nk = RAGGED ? (g.K + BK - 1) / BK : g.K / BK;   // (plain form: whole k-tiles only, the launcher checks)
+  const int64_t nk = RAGGED == 1 ? (g.K + BK - 1) / BK : g.K / BK;   // (forms 0 and 2: whole k-tiles only, the launcher checks)
 #pragma unroll
-  for (int i = 0; i < PA; ++i) glds_tile_pass<BM, BK, NT, RAGGED>(A, g.a_ks, m0, 0, &A0[0][0], i, g.M, g.K, g.zero);
+  for (int i = 0; i < PA; ++i) glds_tile_pass<BM, BK, NT, RAGGED != 0>(A, g.a_ks, m0, 0, &A0[0][0], i, g.M, g.K, g.zero);
 #pragma unroll
-  for (int i = 0; i < PB; ++i) glds_tile_pass<BN, BK, NT, RAGGED>(B, g.b_ks, n0, 0, &B0[0][0], i, g.N, g.K, g.zero);
+  for (int i = 0; i < PB; ++i) glds_tile_pass<BN, BK, NT, RAGGED != 0>(B, g.b_ks, n0, 0, &B0[0][0], i, g.N, g.K, g.zero);
   const uint32_t la = glds_tile_lane_off<BM>(g.a_ks), lb = glds_tile_lane_off<BN>(g.b_ks);   // per-lane parts of the DMA addresses (loop-invariant)
   const int uw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float *wa = A + m0 + (int64_t)uw * (256 / BM) * g.a_ks, *wb = B + n0 + (int64_t)uw * (256 / BN) * g.b_ks;   // uniform parts
   const int64_t sa = (int64_t)(NT / 64) * (256 / BM) * g.a_ks, sb = (int64_t)(NT / 64) * (256 / BN) * g.b_ks;
+  // rows-only ragged form: which lanes' four rows lie inside the operands (the same lanes in every piece of a [k][row] image)
+  bool pra = true, prb = true;
+  if constexpr (RAGGED == 2) {
+    pra = m0 + (int64_t)((threadIdx.x & 63) % (BM / 4 > 64 ? 64 : BM / 4)) * 4 < g.M;
+    prb = n0 + (int64_t)((threadIdx.x & 63) % (BN / 4 > 64 ? 64 : BN / 4)) * 4 < g.N;
+  }
   __syncthreads();
 
   // fragments for TWO steps (4 k) per LDS instruction: rows 4p+h and 4p+2+h of the [k][row] image lie 2*ROWS floats apart, a
@@ -544,11 +554,13 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
         for (int q = 0; q < PPS; ++q) {
           const int pi = sidx * PPS + q;
           if (pi < PA) {
-            if constexpr (RAGGED) glds_tile_pass<BM, BK, NT, true>(A, g.a_ks, m0, kn * BK, CUR ? &A0[0][0] : &A1[0][0], pi, g.M, g.K, g.zero);
+            if constexpr (RAGGED == 1) glds_tile_pass<BM, BK, NT, true>(A, g.a_ks, m0, kn * BK, CUR ? &A0[0][0] : &A1[0][0], pi, g.M, g.K, g.zero);
+            else if constexpr (RAGGED == 2) glds_tile_pass_u<BM, BK, NT>(wa, sa, kn * BK * g.a_ks, CUR ? &A0[0][0] : &A1[0][0], pi, la, pra);
             else glds_tile_pass_u<BM, BK, NT>(wa, sa, kn * BK * g.a_ks, CUR ? &A0[0][0] : &A1[0][0], pi, la);
             ++n_dma;
           } else if (pi < PA + PB) {
-            if constexpr (RAGGED) glds_tile_pass<BN, BK, NT, true>(B, g.b_ks, n0, kn * BK, CUR ? &B0[0][0] : &B1[0][0], pi - PA, g.N, g.K, g.zero);
+            if constexpr (RAGGED == 1) glds_tile_pass<BN, BK, NT, true>(B, g.b_ks, n0, kn * BK, CUR ? &B0[0][0] : &B1[0][0], pi - PA, g.N, g.K, g.zero);
+            else if constexpr (RAGGED == 2) glds_tile_pass_u<BN, BK, NT>(wb, sb, kn * BK * g.b_ks, CUR ? &B0[0][0] : &B1[0][0], pi - PA, lb, prb);
             else glds_tile_pass_u<BN, BK, NT>(wb, sb, kn * BK * g.b_ks, CUR ? &B0[0][0] : &B1[0][0], pi - PA, lb);
             ++n_dma;
           }
@@ -586,7 +598,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wm * (WTM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (!RAGGED || (row < g.M && col < g.N)) C[row * g.c_ms + col * g.c_ns] = acc[i][j][r];
+        if (RAGGED == 0 || (row < g.M && col < g.N)) C[row * g.c_ms + col * g.c_ns] = acc[i][j][r];
       }
     }
 }
@@ -619,21 +631,22 @@ __device__ __forceinline__ uint32_t glds_kc_lane_off(int64_t rs) {
   return (uint32_t)(((int64_t)(lane & 15) * rs + (lane >> 4) * 4) * 4);
 }
 // `wbase` = P + (row0 + wave * 16) * rs (uniform), `step` = NW * 16 * rs floats between a wave's 16-row blocks, `k0` = first k of the tile
-template <int ROWS, int BK, int NT>
-__device__ __forceinline__ void glds_kc_pass_u(const float *wbase, int64_t step, int64_t k0, float *S, int i, uint32_t lane_off) {
+template <int ROWS, int BK, int NT, bool PRED = false>
+__device__ __forceinline__ void glds_kc_pass_u(const float *wbase, int64_t step, int64_t k0, float *S, int i, uint32_t lane_off, int rows_left = 0) {
   constexpr int NW = NT / 64, KH = BK / 16;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int rb = (i / KH) * NW + wave, kh = i % KH;
   const char *ub = reinterpret_cast<const char *>(wbase + (int64_t)(i / KH) * step + k0 + kh * 16);
   asm("" : "+v"(lane_off) : "s"((int)k0));   // (as in glds_tile_pass_u)
-  __builtin_amdgcn_global_load_lds((md_gbl_void *)(ub + lane_off), (md_lds_void *)(S + (rb * KH + kh) * 256), 16, 0, 0);
+  // `rows_left` = rows of the operand from this tile's first row on (rows-only ragged kernels; see glds_tile_pass_u)
+  if (!PRED || (int)(threadIdx.x & 15) + rb * 16 < rows_left) __builtin_amdgcn_global_load_lds((md_gbl_void *)(ub + lane_off), (md_lds_void *)(S + (rb * KH + kh) * 256), 16, 0, 0);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool B_KC, int EPI = 0, bool RAGGED = false>
+template <int BM, int BN, int BK, int WM, int WN, bool B_KC, int EPI = 0, int RAGGED = 0>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);
-  constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NSTEP = BK / 2, NP = BK / 8, KH = BK / 16;
+  constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NP = BK / 8, KH = BK / 16;
   // the next tile's DMA pieces go out within the first DMA_STEPS steps of the k-tile (16 steps at BK 32); same-box A/B at 4096^3 NT,
   // r2_gemm_glds_ab.log: 16 steps 138.9 | 8: 144.6 | 4: 146.0 | 3: 145.5 | 2: 143.8 | 1: 140.4 TFLOP/s
   constexpr int DMA_STEPS = 4;   // (re-checked after the scalar-base addressing: 2 -> NT 146.7, 8 -> 147.9, 4 -> 149.2; all of the
@@ -680,21 +693,29 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int64_t nk = RAGGED ? (g.K + BK - 1) / BK : g.K / BK;
+  const int64_t nk = RAGGED == 1 ? (g.K + BK - 1) / BK : g.K / BK;
   unsigned long long st_c = 0, st_r = 0;   // diagnostic stamps (MDHIP_GEMM_STAMP=1), as in k_gemm_f32_mfma
   if (g.stamp) { st_c = __builtin_amdgcn_s_memtime(); st_r = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll
-  for (int i = 0; i < PA; ++i) glds_kc_pass<BM, BK, NT, RAGGED>(A, g.a_ms, m0, 0, A0, i, g.M, g.K, g.zero);
+  for (int i = 0; i < PA; ++i) glds_kc_pass<BM, BK, NT, RAGGED != 0>(A, g.a_ms, m0, 0, A0, i, g.M, g.K, g.zero);
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
-    if constexpr (B_KC) glds_kc_pass<BN, BK, NT, RAGGED>(B, g.b_ns, n0, 0, B0, i, g.N, g.K, g.zero);
-    else glds_tile_pass<BN, BK, NT, RAGGED>(B, g.b_ks, n0, 0, B0, i, g.N, g.K, g.zero);
+    if constexpr (B_KC) glds_kc_pass<BN, BK, NT, RAGGED != 0>(B, g.b_ns, n0, 0, B0, i, g.N, g.K, g.zero);
+    else glds_tile_pass<BN, BK, NT, RAGGED != 0>(B, g.b_ks, n0, 0, B0, i, g.N, g.K, g.zero);
   }
   const uint32_t la = glds_kc_lane_off(g.a_ms), lb = B_KC ? glds_kc_lane_off(g.b_ns) : glds_tile_lane_off<BN>(g.b_ks);   // (loop-invariant lane parts of the DMA addresses)
   const int uw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float *wa = A + (m0 + (int64_t)uw * 16) * g.a_ms;   // uniform parts: adds only inside the loop
   const float *wb = B_KC ? B + (n0 + (int64_t)uw * 16) * g.b_ns : B + n0 + (int64_t)uw * (256 / BN) * g.b_ks;
   const int64_t sa = (int64_t)(NT / 64) * 16 * g.a_ms, sb = B_KC ? (int64_t)(NT / 64) * 16 * g.b_ns : (int64_t)(NT / 64) * (256 / BN) * g.b_ks;
+  // rows-only ragged form (RAGGED == 2): rows of the operands from this tile's first row on / lanes of the [k][n] image inside B
+  int rla = 0, rlb = 0;
+  bool prb = true;
+  if constexpr (RAGGED == 2) {
+    rla = (int)(g.M - m0 < (1 << 30) ? g.M - m0 : (1 << 30));
+    rlb = (int)(g.N - n0 < (1 << 30) ? g.N - n0 : (1 << 30));
+    if constexpr (!B_KC) prb = n0 + (int64_t)((threadIdx.x & 63) % (BN / 4 > 64 ? 64 : BN / 4)) * 4 < g.N;
+  }
   __syncthreads();
 
   f32x4 fa[2][WTM], fb[2][WTN];
@@ -730,13 +751,17 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
           const int pi = sidx * PPS + q;
 #ifndef MD_ABL_NODMA
           if (pi < PA) {
-            if constexpr (RAGGED) glds_kc_pass<BM, BK, NT, true>(A, g.a_ms, m0, kn * BK, CUR ? A0 : A1, pi, g.M, g.K, g.zero);
+            if constexpr (RAGGED == 1) glds_kc_pass<BM, BK, NT, true>(A, g.a_ms, m0, kn * BK, CUR ? A0 : A1, pi, g.M, g.K, g.zero);
+            else if constexpr (RAGGED == 2) glds_kc_pass_u<BM, BK, NT, true>(wa, sa, kn * BK, CUR ? A0 : A1, pi, la, rla);
             else glds_kc_pass_u<BM, BK, NT>(wa, sa, kn * BK, CUR ? A0 : A1, pi, la);
             ++n_dma;
           } else if (pi < PA + PB) {
-            if constexpr (RAGGED) {
+            if constexpr (RAGGED == 1) {
               if constexpr (B_KC) glds_kc_pass<BN, BK, NT, true>(B, g.b_ns, n0, kn * BK, CUR ? B0 : B1, pi - PA, g.N, g.K, g.zero);
               else glds_tile_pass<BN, BK, NT, true>(B, g.b_ks, n0, kn * BK, CUR ? B0 : B1, pi - PA, g.N, g.K, g.zero);
+            } else if constexpr (RAGGED == 2) {
+              if constexpr (B_KC) glds_kc_pass_u<BN, BK, NT, true>(wb, sb, kn * BK, CUR ? B0 : B1, pi - PA, lb, rlb);
+              else glds_tile_pass_u<BN, BK, NT>(wb, sb, kn * BK * g.b_ks, CUR ? B0 : B1, pi - PA, lb, prb);
             } else {
               if constexpr (B_KC) glds_kc_pass_u<BN, BK, NT>(wb, sb, kn * BK, CUR ? B0 : B1, pi - PA, lb);
               else glds_tile_pass_u<BN, BK, NT>(wb, sb, kn * BK * g.b_ks, CUR ? B0 : B1, pi - PA, lb);
@@ -797,7 +822,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wm * (WTM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (!RAGGED || (row < g.M && col < g.N)) C[row * g.c_ms + col * g.c_ns] = acc[i][j][r];
+        if (RAGGED == 0 || (row < g.M && col < g.N)) C[row * g.c_ms + col * g.c_ns] = acc[i][j][r];
       }
     }
 }
@@ -945,7 +970,10 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
       const char *e = getenv("MDHIP_GEMM_GLDS");
       ragged_dma = edge && aligned && (e ? atoi(e) != 0 : true) && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp && ga.M % 4 == 0 && ga.N % 4 == 0 && ga.a_ks > 0 && ga.b_ks > 0 &&
                    (ga.zero = md_zero_block()) != nullptr;
-      if (ragged_dma) md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN, true>, grid, 64 * WM * WN, ga);
+      if (ragged_dma) {
+        if (ga.K % BK == 0) md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN, 2>, grid, 64 * WM * WN, ga);   // (whole k-tiles: predicated lanes, fast addresses)
+        else md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN, 1>, grid, 64 * WM * WN, ga);
+      }
     }
     if (ragged_dma) {
     } else if (edge) md_gemm_launch(k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, true>, grid, 64 * WM * WN, ga);
@@ -1037,7 +1065,8 @@ static int launch_kc_glds(GemmArgs ga, int64_t batch, bool edge) {
   }
   if constexpr (EPI == 0) {
     if (ragged) {
-      md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, 0, true>, grid, 64 * WM * WN, ga);
+      if (ga.K % BK == 0) md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, 0, 2>, grid, 64 * WM * WN, ga);   // (whole k-tiles: predicated lanes, fast addresses)
+      else md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, 0, 1>, grid, 64 * WM * WN, ga);
       return MD_LAUNCH_CHECK("matmul(f32 mfma, direct-to-LDS, ragged)");
     }
   }
