@@ -441,7 +441,7 @@ template <int ROWS> __device__ __forceinline__ uint32_t glds_tile_lane_off(int64
 }
 // `wbase` = the wave's first piece of tile 0 (uniform pointer: P + row0 + wave * KPP * ks), `step` = floats between a wave's consecutive
 // pieces (NW * KPP * ks), `koff` = floats from tile 0 to this k-tile (k0 * ks): adds only, in scalar registers.
-template <int ROWS, int BK, int NT>
+template <int ROWS, int BK, int NT, bool PRED = false>
 __device__ __forceinline__ void glds_tile_pass_u(const float *wbase, int64_t step, int64_t koff, float *S, int i, uint32_t lane_off, bool pred = true) {
   constexpr int NW = NT / 64;
   static_assert(ROWS <= 256, "a piece covers whole k-rows");
@@ -453,7 +453,11 @@ __device__ __forceinline__ void glds_tile_pass_u(const float *wbase, int64_t ste
   asm("" : "+v"(lane_off) : "s"((int)koff));
   // `pred` (rows-only ragged kernels): a lane whose four rows lie outside the operand fetches nothing — its LDS slot keeps whatever an
   // earlier tile left there, which only reaches outputs outside C (row m of A feeds row m of C alone, column n of B column n alone)
-  if (pred) __builtin_amdgcn_global_load_lds((md_gbl_void *)(ub + lane_off), (md_lds_void *)(S + (i * NW + wave) * 256), 16, 0, 0);
+  if constexpr (PRED) {
+    if (pred) __builtin_amdgcn_global_load_lds((md_gbl_void *)(ub + lane_off), (md_lds_void *)(S + (i * NW + wave) * 256), 16, 0, 0);
+  } else {
+    __builtin_amdgcn_global_load_lds((md_gbl_void *)(ub + lane_off), (md_lds_void *)(S + (i * NW + wave) * 256), 16, 0, 0);
+  }
 }
 
 template <int V> struct MdInt { static constexpr int value = V; };
@@ -555,12 +559,12 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
           const int pi = sidx * PPS + q;
           if (pi < PA) {
             if constexpr (RAGGED == 1) glds_tile_pass<BM, BK, NT, true>(A, g.a_ks, m0, kn * BK, CUR ? &A0[0][0] : &A1[0][0], pi, g.M, g.K, g.zero);
-            else if constexpr (RAGGED == 2) glds_tile_pass_u<BM, BK, NT>(wa, sa, kn * BK * g.a_ks, CUR ? &A0[0][0] : &A1[0][0], pi, la, pra);
+            else if constexpr (RAGGED == 2) glds_tile_pass_u<BM, BK, NT, true>(wa, sa, kn * BK * g.a_ks, CUR ? &A0[0][0] : &A1[0][0], pi, la, pra);
             else glds_tile_pass_u<BM, BK, NT>(wa, sa, kn * BK * g.a_ks, CUR ? &A0[0][0] : &A1[0][0], pi, la);
             ++n_dma;
           } else if (pi < PA + PB) {
             if constexpr (RAGGED == 1) glds_tile_pass<BN, BK, NT, true>(B, g.b_ks, n0, kn * BK, CUR ? &B0[0][0] : &B1[0][0], pi - PA, g.N, g.K, g.zero);
-            else if constexpr (RAGGED == 2) glds_tile_pass_u<BN, BK, NT>(wb, sb, kn * BK * g.b_ks, CUR ? &B0[0][0] : &B1[0][0], pi - PA, lb, prb);
+            else if constexpr (RAGGED == 2) glds_tile_pass_u<BN, BK, NT, true>(wb, sb, kn * BK * g.b_ks, CUR ? &B0[0][0] : &B1[0][0], pi - PA, lb, prb);
             else glds_tile_pass_u<BN, BK, NT>(wb, sb, kn * BK * g.b_ks, CUR ? &B0[0][0] : &B1[0][0], pi - PA, lb);
             ++n_dma;
           }
@@ -761,7 +765,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
               else glds_tile_pass<BN, BK, NT, true>(B, g.b_ks, n0, kn * BK, CUR ? B0 : B1, pi - PA, g.N, g.K, g.zero);
             } else if constexpr (RAGGED == 2) {
               if constexpr (B_KC) glds_kc_pass_u<BN, BK, NT, true>(wb, sb, kn * BK, CUR ? B0 : B1, pi - PA, lb, rlb);
-              else glds_tile_pass_u<BN, BK, NT>(wb, sb, kn * BK * g.b_ks, CUR ? B0 : B1, pi - PA, lb, prb);
+              else glds_tile_pass_u<BN, BK, NT, true>(wb, sb, kn * BK * g.b_ks, CUR ? B0 : B1, pi - PA, lb, prb);
             } else {
               if constexpr (B_KC) glds_kc_pass_u<BN, BK, NT>(wb, sb, kn * BK, CUR ? B0 : B1, pi - PA, lb);
               else glds_tile_pass_u<BN, BK, NT>(wb, sb, kn * BK * g.b_ks, CUR ? B0 : B1, pi - PA, lb);
@@ -971,7 +975,10 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
       ragged_dma = edge && aligned && (e ? atoi(e) != 0 : true) && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp && ga.M % 4 == 0 && ga.N % 4 == 0 && ga.a_ks > 0 && ga.b_ks > 0 &&
                    (ga.zero = md_zero_block()) != nullptr;
       if (ragged_dma) {
-        if (ga.K % BK == 0) md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN, 2>, grid, 64 * WM * WN, ga);   // (whole k-tiles: predicated lanes, fast addresses)
+        // whole k-tiles on the 128-row tiles: predicated lanes + scalar-base addresses (4100 x 4096 x 4100: 104-108 -> 112-124 TFLOP/s);
+        // the 256x256 tile keeps the select form — the predicate's branch around each DMA splits its one scheduling region
+        // (4000^3: 133-137 against 130 with the predicate)
+        if (ga.K % BK == 0 && BM <= 128) md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN, 2>, grid, 64 * WM * WN, ga);
         else md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN, 1>, grid, 64 * WM * WN, ga);
       }
     }
@@ -1065,7 +1072,7 @@ static int launch_kc_glds(GemmArgs ga, int64_t batch, bool edge) {
   }
   if constexpr (EPI == 0) {
     if (ragged) {
-      if (ga.K % BK == 0) md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, 0, 2>, grid, 64 * WM * WN, ga);   // (whole k-tiles: predicated lanes, fast addresses)
+      if (ga.K % BK == 0 && BM <= 128) md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, 0, 2>, grid, 64 * WM * WN, ga);   // (as in launch_cfg's TN branch)
       else md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, 0, 1>, grid, 64 * WM * WN, ga);
       return MD_LAUNCH_CHECK("matmul(f32 mfma, direct-to-LDS, ragged)");
     }
