@@ -195,9 +195,10 @@ template <class R, class T> __device__ __forceinline__ T vm_block_reduce(T v, T 
 }
 
 template <class R, class T>
-__global__ void __launch_bounds__(MD_BLOCK) k_vm_reduce_all(MdVmDev P, int64_t rows, int64_t inner, T *partial) {
+__global__ void __launch_bounds__(MD_BLOCK) k_vm_reduce_all(MdVmDev P, int64_t rows, int64_t inner, T *partial, unsigned *tickets, T *out) {
   MD_VM_PROLOGUE;
   __shared__ T smem[MD_BLOCK / 64];
+  __shared__ unsigned last_flag;
   const int64_t nv = inner >> 2, total = rows * nv;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gs = (int64_t)gridDim.x * blockDim.x;
   T a[VW];
@@ -237,13 +238,11 @@ __global__ void __launch_bounds__(MD_BLOCK) k_vm_reduce_all(MdVmDev P, int64_t r
     }
   }
   acc = vm_block_reduce<R>(acc, smem);
-  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
-}
-template <class R, class T>
-__global__ void __launch_bounds__(MD_BLOCK) k_vm_finish_all(const T *partial, int64_t n, T *out) {
-  __shared__ T smem[MD_BLOCK / 64];
-  T acc = R::template identity<T>();
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc = R::combine(acc, partial[i]);
+  // block partials -> the block that arrives last sums them in index order (md_ticket.h): no finishing launch
+  if (threadIdx.x == 0) md_st_sc1(partial + blockIdx.x, acc);
+  const bool last = gridDim.x >= 64 ? md_ticket_last2(tickets, blockIdx.x, gridDim.x, &last_flag) : md_ticket_last(tickets, gridDim.x, &last_flag);
+  if (!last) return;
+  acc = md_fold_partials<R>(partial, gridDim.x);
   acc = vm_block_reduce<R>(acc, smem);
   if (threadIdx.x == 0) out[0] = acc;
 }
@@ -304,8 +303,6 @@ __global__ void __launch_bounds__(MD_BLOCK) k_vm_reduce_cols(MdVmDev P, int64_t 
     *reinterpret_cast<MdVec<T, 4> *>(d) = o;
   }
 }
-
-#include "md_cols_merge.h"
 
 }  // namespace
 #include "fusion_jit.inc"
@@ -489,18 +486,19 @@ static bool uncollapse_2d(const MdVmIter &it, int n_leaves, MdVmDev *D, int64_t 
   return true;
 }
 
-// Sweep geometry for a (n_red x n_out) program: n_out = Q x 1024 elements (Q column vectors per lane of a 256-thread
-// block), a contiguous band of rows per block, one block per CU.
-static bool sweep_geometry(int64_t n_out, int64_t n_red, int *Q, int64_t *nblk, int64_t *chunk) {
-  if (n_out % 1024 || n_red < 512) return false;
-  const int64_t q = n_out / 1024;
-  if (q != 1 && q != 2 && q != 4 && q != 8) return false;
-  *Q = (int)q;
-  static const int per_cu = [] { const char *e = getenv("MDHIP_SWEEP_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 1; return v == 2 ? 2 : 1; }();
-  int64_t nb = MD_NUM_CUS * per_cu;   // (the merge pass takes up to 512 partial rows)
-  if (nb > n_red / 6) nb = n_red / 6;
-  *chunk = (n_red + nb - 1) / nb;
-  *nblk = (n_red + *chunk - 1) / *chunk;
+// Strip geometry for a (n_red x n_out) program (the generated SWEEP kernel, fusion_jit.inc): NS strips of 256 columns x NB
+// interleaved row bands, one block per CU, <= 64 bands (the last block of a strip holds its partial rows in registers).
+static bool sweep_geometry(int64_t n_out, int64_t n_red, int ru, int64_t *NS, int64_t *NB) {
+  if ((n_out & 3) || n_out < 4 || n_red < 512) return false;
+  static const int nb_force = [] { const char *e = getenv("MDHIP_SWEEP_NB"); return e ? atoi(e) : 0; }();
+  const int64_t ns = (n_out + 255) / 256;
+  int64_t nb = nb_force > 0 ? nb_force : (ns >= MD_NUM_CUS ? 1 : MD_NUM_CUS / ns);
+  if (nb > 64) nb = 64;
+  if (nb > n_red / (4 * ru)) nb = n_red / (4 * ru);
+  if (nb < 1) nb = 1;
+  if (ns * nb >= (1ll << 31) || (nb > 1 && ns * MD_TICKET_PAD > MD_TICKET_WORDS)) return false;
+  *NS = ns;
+  *NB = nb;
   return true;
 }
 
@@ -509,27 +507,26 @@ static bool sweep_geometry(int64_t n_out, int64_t n_red, int *Q, int64_t *nblk, 
 template <class R, class T>
 static bool sweep_cols(const mdhip_vm_program *pr, int rop, const MdVmDev &D, int64_t rows, int64_t inner, void *eval_out,
                        const mdhip_array *out, int *status) {
-  int Q;
-  int64_t nblk, chunk;
-  if (!jit::enabled() || rows * inner < jit::min_elems() || !sweep_geometry(inner, rows, &Q, &nblk, &chunk)) return false;
+  if (!jit::enabled() || rows * inner < jit::min_elems()) return false;
   jit::Spec S;
   S.kind = jit::SWEEP;
   jit::spec_single(&S, pr);
   jit::spec_modes(&S, D, rows);
   S.rop = rop;
   S.store = eval_out != nullptr;
-  S.Q = Q;
   int64_t bytes = eval_out ? rows * inner * (int64_t)sizeof(T) : 0;
   for (int l = 0; l < pr->n_leaves; ++l)
     if (S.leaf_mode[l] == jit::LM_VEC) bytes += rows * inner * (int64_t)md_dtype_size(pr->leaves[l].dtype);
-  // rows per trip: ~192 B of loads in flight per lane (a bool leaf brings 4 B per column vector, a float leaf 16)
+  // rows per trip: ~128 B of loads in flight per lane (a bool leaf brings 4 B per row, a float leaf 16)
   int64_t row_bytes = 0;
   for (int l = 0; l < pr->n_leaves; ++l)
-    if (S.leaf_mode[l] == jit::LM_VEC) row_bytes += (int64_t)Q * 4 * (int64_t)md_dtype_size(pr->leaves[l].dtype);
+    if (S.leaf_mode[l] == jit::LM_VEC) row_bytes += 4 * (int64_t)md_dtype_size(pr->leaves[l].dtype);
   static const int ru_env = [] { const char *e = getenv("MDHIP_SWEEP_RU"); return e ? atoi(e) : 0; }();
-  S.RU = ru_env > 0 ? ru_env : (row_bytes > 0 ? (int)((192 + row_bytes - 1) / row_bytes) : 1);
+  S.RU = ru_env > 0 ? ru_env : (row_bytes > 0 ? (int)((128 + row_bytes - 1) / row_bytes) : 1);
   if (S.RU > 8) S.RU = 8;
   if (S.RU < 1) S.RU = 1;
+  int64_t NS, NB;
+  if (!sweep_geometry(inner, rows, S.RU, &NS, &NB)) return false;
   S.nt = bytes > ((int64_t)320 << 20);
   // the evaluated value of a one-pass eval + column reduce is a large write next to (often much smaller) reads, and its
   // reader is whatever needed it in memory (cfg4: the weight-gradient GEMM, which is not bandwidth-bound): written around
@@ -539,20 +536,19 @@ static bool sweep_cols(const mdhip_vm_program *pr, int rop, const MdVmDev &D, in
   hipFunction_t fn = jit::get(S);
   if (!fn) return false;
   void *partial = nullptr;
-  *status = mdhip_alloc((size_t)(nblk * inner) * sizeof(T), &partial);
-  if (*status != MDHIP_OK) return true;
+  if (NB > 1) {
+    *status = mdhip_alloc((size_t)(NB * inner) * sizeof(T), &partial);
+    if (*status != MDHIP_OK) return true;
+  }
   jit::JArgs A;
   jit::fill_args(&A, pr, D);
-  A.rows = rows; A.inner = inner; A.n_out = inner; A.n_red = rows; A.chunk = chunk;
-  A.out = partial;
+  A.rows = rows; A.inner = inner; A.n_out = inner; A.n_red = rows; A.chunk = NB;
+  A.out = out->data;
   A.outs[0] = eval_out;
-  *status = jit::launch(fn, A, dim3((unsigned)nblk));
-  if (*status == MDHIP_OK) {
-    if (nblk <= 256) k_reduce_cols_merge<R, T, T, 16><<<(unsigned)((inner + 63) / 64), 1024, 0, md_stream()>>>((const T *)partial, inner, nblk, (T *)out->data);
-    else k_reduce_cols_merge<R, T, T, 32><<<(unsigned)((inner + 63) / 64), 1024, 0, md_stream()>>>((const T *)partial, inner, nblk, (T *)out->data);
-    *status = MD_LAUNCH_CHECK("vm_reduce(cols,sweep)");
-  }
-  mdhip_free(partial);
+  A.partial = partial;
+  A.tickets = md_tickets();
+  *status = jit::launch(fn, A, dim3((unsigned)(NS * NB)));
+  if (partial) mdhip_free(partial);  // stream-ordered
   return true;
 }
 
@@ -593,15 +589,16 @@ static int reduce_typed(const mdhip_vm_program *pr, int rop, const mdhip_array *
     }
     void *partial = nullptr;
     MD_TRY(mdhip_alloc((size_t)grid * sizeof(T), &partial));
+    int rc;
     if (fn) {
-      A.out = partial;
-      int rc = jit::launch(fn, A, dim3((unsigned)grid));
-      if (rc != MDHIP_OK) { mdhip_free(partial); return rc; }
+      A.out = out->data;
+      A.partial = partial;
+      A.tickets = md_tickets();
+      rc = jit::launch(fn, A, dim3((unsigned)grid));
     } else {
-      k_vm_reduce_all<R, T><<<grid, MD_BLOCK, 0, st>>>(D, rows, inner, (T *)partial);
+      k_vm_reduce_all<R, T><<<grid, MD_BLOCK, 0, st>>>(D, rows, inner, (T *)partial, md_tickets(), (T *)out->data);
+      rc = MD_LAUNCH_CHECK("vm_reduce(all)");
     }
-    k_vm_finish_all<R, T><<<1, MD_BLOCK, 0, st>>>((const T *)partial, grid, (T *)out->data);
-    int rc = MD_LAUNCH_CHECK("vm_reduce(all)");
     mdhip_free(partial);
     return rc;
   }

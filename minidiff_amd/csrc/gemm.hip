@@ -67,6 +67,8 @@ struct GemmArgs {
   const float *bias;
   uint8_t *mask;
   float *partial;
+  float *sum_out;     // the 0-d result, written by the block that arrives last at `tickets` (md_ticket.h)
+  unsigned *tickets;
   // diagnostic (MDHIP_GEMM_STAMP=1, never set in production): per block {shader cycles, 100 MHz ticks} around the whole kernel body
   unsigned long long *stamp;
   // ragged direct-to-LDS kernels: 16 B of zeros in device memory — what a DMA lane fetches for a position outside the operand
@@ -139,7 +141,7 @@ __device__ __forceinline__ void store_tile(float (*S)[ROWS + LDP], const f32x4 (
 // Fused epilogue of  loss = sum(where(X @ W + b > 0, X @ W + b, 0))  (reference call pattern: matmul
 // definitions.py:487-492 -> add :424-427 -> greater :468-471 -> where :555-559 -> sum :403-407): the pre-activation
 // never goes to memory; what the backward pass needs of it — the mask — does, as numpy.bool_ bytes, and the block's
-// relu sum goes to partial[blockIdx.x] (summed in index order by k_gemm_epi_finish).
+// relu sum goes to partial[blockIdx.x]; the block that finishes last sums the partials in index order into sum_out.
 // The accumulator layout gives a lane ONE column and 16 rows: written as it stands the mask would go out in 32-byte
 // pieces of single bytes (measured: +106 us on the 8192 x 4096 x 4096 product). Instead the four lanes of a quad
 // exchange their 16 result bits, each lane packs the 4 adjacent columns of 4 of the rows into one dword, the tile's
@@ -211,7 +213,22 @@ __device__ __forceinline__ void md_epi_bias_relu(const f32x16 (&acc)[BM / (32 * 
     float t = 0.0f;
 #pragma unroll
     for (int w = 0; w < WM * WN; ++w) t += red[w];
-    g.partial[blockIdx.x] = t;
+    md_st_sc1(g.partial + blockIdx.x, t);
+  }
+  // the block that arrives last sums the per-block partials in index order (md_ticket.h): no finishing launch
+  unsigned *flag = reinterpret_cast<unsigned *>(red + 32);
+  const unsigned nblk = gridDim.x;
+  if (!(nblk >= 64 ? md_ticket_last2(g.tickets, blockIdx.x, nblk, flag) : md_ticket_last(g.tickets, nblk, flag))) return;
+  float t = md_fold_partials<RSum>(g.partial, nblk);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d, 64);
+  if (lane == 0) red[wave] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WM * WN; ++w) tot += red[w];
+    g.sum_out[0] = tot;
   }
 }
 
@@ -1377,36 +1394,19 @@ extern "C" int mdhip_matmul(const mdhip_array *a, const mdhip_array *b, const md
 }
 
 namespace {
-// sum of the per-block partials in index order (one block: deterministic)
-__global__ void __launch_bounds__(MD_BLOCK) k_gemm_epi_finish(const float *__restrict__ partial, int64_t n, float *__restrict__ out) {
-  __shared__ float sm[MD_BLOCK];
-  float acc = 0.0f;
-  for (int64_t i = threadIdx.x; i < n; i += MD_BLOCK) acc += partial[i];
-  sm[threadIdx.x] = acc;
-  __syncthreads();
-  for (int d = MD_BLOCK / 2; d > 0; d >>= 1) {
-    if ((int)threadIdx.x < d) sm[threadIdx.x] += sm[threadIdx.x + d];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[0] = sm[0];
-}
-
 template <int BM, int BN, int WM = 2, int WN = 2, bool DMA = false> static int launch_epi(GemmArgs ga) {
   const int64_t tiles = ((ga.M + BM - 1) / BM) * ((ga.N + BN - 1) / BN);
   void *partial = nullptr;
   MD_TRY(mdhip_alloc((size_t)tiles * sizeof(float), &partial));
-  float *out = ga.partial;  // (the caller parked the 0-d result pointer here)
+  ga.sum_out = ga.partial;  // (the caller parked the 0-d result pointer here)
   ga.partial = (float *)partial;
+  ga.tickets = md_tickets();
   int rc;
   if constexpr (DMA) {
     rc = launch_kc_glds<BM, BN, WM, WN, false, 1>(ga, 1, false);   // (the caller checked whole tiles and alignment)
     if (rc < 0) rc = md_fail(MDHIP_EVALUE, "matmul_bias_relu_sum: shape not covered by the fused kernel");
   }
   else rc = launch_cfg<BM, BN, 16, WM, WN, true, false, BM == 64 ? 0 : 1, 1>(ga, 1, false);
-  if (rc == MDHIP_OK) {
-    k_gemm_epi_finish<<<1, MD_BLOCK, 0, md_stream()>>>((const float *)partial, tiles, out);
-    rc = MD_LAUNCH_CHECK("matmul(bias+relu epilogue, finish)");
-  }
   mdhip_free(partial);
   return rc;
 }

@@ -5,7 +5,10 @@
 
 #include "md_dispatch.h"
 
+#include "md_ticket.h"
+
 hipStream_t md_stream();
+unsigned *md_tickets();                                   // MD_TICKET_WORDS zeroed counters (md_ticket.h)
 bool md_prof_take(hipEvent_t *start, hipEvent_t *stop);   // bench timing: events for the next GEMM kernel, if any were attached
 int md_hip_check(hipError_t e, const char *what);
 

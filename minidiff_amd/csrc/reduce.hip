@@ -57,9 +57,14 @@ template <bool NT, class V> __device__ __forceinline__ V md_ld_once(const V *p) 
   }
 }
 
-template <class R, class Tacc, class Tdst, bool FINAL, bool NT = false>
-__global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows(MdRedPlan pl, const void *x, int xdt, int64_t splits, Tdst *dst) {
+// MODE 0: one block per output, dst = the output. MODE 1: `splits` blocks per output leave partials in dst (finished by
+// k_finish_rows: 1-byte accumulators). MODE 2: partials + ticket (md_ticket.h): the block that arrives last at its output's
+// counter sums the output's partials in index order — the finishing pass without its launch (4.7 us + the launch boundary
+// on cfg4's 128 MiB loss sum; same summation order as k_finish_rows, so the results did not change).
+template <class R, class Tacc, class Tdst, int MODE, bool NT = false>
+__global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows(MdRedPlan pl, const void *x, int xdt, int64_t splits, Tdst *dst, Tacc *partial, unsigned *tickets) {
   __shared__ Tacc smem[MD_BLOCK / 64];
+  __shared__ unsigned last_flag;
   const int64_t b = blockIdx.x;
   const int64_t o = b / splits, s = b - o * splits;
   int64_t xo, oo;
@@ -109,9 +114,18 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows(MdRedPlan pl, const vo
     for (int64_t r = lane0; r < n; r += step) acc = R::combine(acc, md_load<Tacc>(x, xdt, xo + md_red_offset(pl, r)));
   }
   acc = md_block_reduce<R>(acc, smem);
-  if (threadIdx.x == 0) {
-    if constexpr (FINAL) dst[oo] = md_cast<Tdst>(acc);
-    else dst[b] = acc;
+  if constexpr (MODE == 0) {
+    if (threadIdx.x == 0) dst[oo] = md_cast<Tdst>(acc);
+  } else if constexpr (MODE == 1) {
+    if (threadIdx.x == 0) dst[b] = md_cast<Tdst>(acc);
+  } else {
+    if (threadIdx.x == 0) md_st_sc1(partial + b, acc);
+    const bool last = splits >= 64 ? md_ticket_last2(tickets + o * MD_TICKET2_WORDS, (unsigned)s, (unsigned)splits, &last_flag)
+                                   : md_ticket_last(tickets + o * MD_TICKET_PAD, (unsigned)splits, &last_flag);
+    if (!last) return;
+    Tacc a = md_fold_partials<R>(partial + o * splits, (unsigned)splits);
+    a = md_block_reduce<R>(a, smem);
+    if (threadIdx.x == 0) dst[oo] = md_cast<Tdst>(a);
   }
 }
 
@@ -232,82 +246,131 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_cols_vec(const Tacc *__rest
   }
 }
 
-// Row-major matrix whose row is exactly Q x 256 vectors (4096 f32 columns: Q = 4): a block sweeps a
-// CONTIGUOUS band of whole rows — the same linear stream as the row kernels — and each lane keeps
-// its Q column vectors in registers (no LDS, no cross-lane step); three rows (3Q 16-B loads per
-// lane) are in flight. One partial row per block, merged by the vector kernel above.
-template <class R, class Tacc, class Tdst, int Q, bool FINAL, bool NT>
-__global__ void __launch_bounds__(MD_BLOCK) k_reduce_cols_sweep(const Tacc *__restrict__ x, int64_t n_out, int64_t n_red, int64_t rs,
-                                                               int64_t chunk, Tdst *__restrict__ dst) {
+// Reduce-to-shape at scale (the bias gradient sum(g[8192, 4096], axis=0) of SURVEY §8 a7), ONE launch.
+// Grid = NS column strips x NB row bands, a band's blocks are neighbours. A strip is 64 lanes x one 16-B vector (1 KiB
+// of a row); the four waves of a block and the NB bands take the rows INTERLEAVED (row = band + NB * (wave + 4 i)), so
+// at any moment the whole grid reads one moving window of the matrix, like the streaming kernels — with a contiguous
+// band per block the same kernel ran at 5.3 TB/s, interleaved at 6.9 (profiles/r3_reduce_lab.txt). Two batches of RB
+// rows are in flight per lane (software pipeline: one wave per SIMD, nothing else covers the issue gap). Waves are
+// combined through LDS in wave order, bands through write-through partial rows and a ticket per strip (md_ticket.h):
+// the block that arrives last at its strip's counter adds the strip's NB partial rows in band order. No atomics on
+// data, fixed order: bit-identical from run to run.
+template <class R, class Tacc, int RB, bool NT>
+__global__ void __launch_bounds__(MD_BLOCK) k_reduce_cols_strips(const Tacc *__restrict__ x, int64_t n_out, int64_t n_red, int64_t rs, int NS,
+                                                                int NB, Tacc *partial, unsigned *tickets, Tacc *__restrict__ out) {
   constexpr int V = 16 / sizeof(Tacc);
-  constexpr int RB = 3;  // rows per batch: RB * Q 16-B loads per lane
-  const int64_t s = blockIdx.x, r0 = s * chunk;
-  int64_t r1 = r0 + chunk;
-  if (r1 > n_red) r1 = n_red;
-  Tacc acc[Q][V];
+  typedef MdVec<Tacc, V> Vec;
+  __shared__ Vec sm[3][64];
+  __shared__ unsigned last_flag;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int s = blockIdx.x % NS, b = blockIdx.x / NS;
+  const int64_t col_raw = ((int64_t)s * 64 + lane) * V;
+  const bool col_ok = col_raw < n_out;
+  const int64_t col = col_ok ? col_raw : n_out - V;  // lanes past a ragged edge load a valid vector and store nothing
+  const int64_t first = b + (int64_t)NB * w, step = (int64_t)NB * 4;
+  const int64_t nrw = first < n_red ? (n_red - first + step - 1) / step : 0;  // rows of this wave: first + step * i
+  const int64_t nb = nrw / RB;
+  Tacc acc[V];
 #pragma unroll
-  for (int q = 0; q < Q; ++q)
+  for (int j = 0; j < V; ++j) acc[j] = R::template identity<Tacc>();
+  const Tacc *p = x + col + first * rs;
+  const int64_t rstep = step * rs;
+  Vec t[2][RB];
+  auto load = [&](int buf, int64_t bt) {
+    const int64_t i0 = (bt < nb ? bt : nb - 1) * RB;  // a prefetch past the end re-reads the last batch (discarded): no branch
 #pragma unroll
-    for (int j = 0; j < V; ++j) acc[q][j] = R::template identity<Tacc>();
-  const MdVec<Tacc, V> *p = reinterpret_cast<const MdVec<Tacc, V> *>(x) + threadIdx.x;
-  const int64_t rsv = rs / V;
-  // Two batches in flight (software pipeline): with one wave per SIMD nothing else covers the gap between "all
-  // loads of this batch have landed" and "the next batch is issued" (one batch per trip ran at 5.0 TB/s). The
-  // batch index of a prefetch past the end is clamped: a redundant, discarded load instead of a branch.
-  const int64_t nb = (r1 - r0) / RB;
-  MdVec<Tacc, V> t[2][RB][Q];
-  auto load = [&](int buf, int64_t b) {
-    const int64_t r = r0 + (b < nb ? b : nb - 1) * RB;
-#pragma unroll
-    for (int u = 0; u < RB; ++u)
-#pragma unroll
-      for (int q = 0; q < Q; ++q) t[buf][u][q] = md_ld_once<NT>(p + (r + u) * rsv + q * MD_BLOCK);
+    for (int u = 0; u < RB; ++u) t[buf][u] = md_ld_once<NT>(reinterpret_cast<const Vec *>(p + (i0 + u) * rstep));
   };
   auto add = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < RB; ++u)
 #pragma unroll
-      for (int q = 0; q < Q; ++q)
-#pragma unroll
-        for (int j = 0; j < V; ++j) acc[q][j] = R::combine(acc[q][j], t[buf][u][q].v[j]);
+      for (int j = 0; j < V; ++j) acc[j] = R::combine(acc[j], t[buf][u].v[j]);
   };
   if (nb > 0) {
     load(0, 0);
-    int64_t b = 0;
-    for (; b + 1 < nb; b += 2) {
-      // (one basic block, and scheduling barriers to pin "issue the next batch, THEN consume the landed one": with
-      // a conditional consumer the compiler sinks the prefetch into the branch, and left alone it sinks loads
-      // behind the adds — either way the queue drains every trip)
-      load(1, b + 1);
+    int64_t bt = 0;
+    for (; bt + 1 < nb; bt += 2) {
+      // (scheduling barriers pin "issue the next batch, THEN consume the landed one"; left alone the compiler sinks the
+      // prefetch behind the adds and the queue drains every trip)
+      load(1, bt + 1);
       __builtin_amdgcn_sched_barrier(0);
       add(0);
       __builtin_amdgcn_sched_barrier(0);
-      load(0, b + 2);
+      load(0, bt + 2);
       __builtin_amdgcn_sched_barrier(0);
       add(1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (b < nb) add(0);  // odd batch count: the last batch sits in buffer 0
+    if (bt < nb) add(0);  // odd batch count: the last batch sits in buffer 0
   }
-  for (int64_t r = r0 + nb * RB; r < r1; ++r) {
+  for (int64_t i = nb * RB; i < nrw; ++i) {
+    const Vec tt = *reinterpret_cast<const Vec *>(p + i * rstep);
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const MdVec<Tacc, V> tt = p[r * rsv + q * MD_BLOCK];
+    for (int j = 0; j < V; ++j) acc[j] = R::combine(acc[j], tt.v[j]);
+  }
+  // waves 1..3 -> wave 0, in wave order
+  if (w > 0) {
 #pragma unroll
-      for (int j = 0; j < V; ++j) acc[q][j] = R::combine(acc[q][j], tt.v[j]);
+    for (int j = 0; j < V; ++j) sm[w - 1][lane].v[j] = acc[j];
+  }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] = R::combine(acc[j], sm[k][lane].v[j]);
+  }
+  if (NB == 1) {
+    if (w == 0 && col_ok) {
+      Vec o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.v[j] = acc[j];
+      *reinterpret_cast<Vec *>(out + col) = o;
+    }
+    return;
+  }
+  const __amdgpu_buffer_rsrc_t pr = md_rsrc(partial, (unsigned)((int64_t)NB * n_out * (int64_t)sizeof(Tacc)));
+  if (w == 0 && col_ok) {
+    Vec o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o.v[j] = acc[j];
+    md_st16_sc1(pr, (unsigned)(((int64_t)b * n_out + col) * (int64_t)sizeof(Tacc)), o);
+  }
+  if (!md_ticket_last(tickets + s * MD_TICKET_PAD, (unsigned)NB, &last_flag)) return;
+  // the strip's NB (<= 64) partial rows: wave w takes rows w, w + 4, ..; every load ahead of the first add
+  Vec pt[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int r = w + 4 * k;
+    if (r < NB) pt[k] = md_ld16_sc1<Vec>(pr, (unsigned)(((int64_t)r * n_out + col) * (int64_t)sizeof(Tacc)));
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = R::template identity<Tacc>();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (w + 4 * k < NB) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] = R::combine(acc[j], pt[k].v[j]);
     }
   }
-  Tdst *d = FINAL ? dst : dst + s * n_out;
+  if (w > 0) {
 #pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    MdVec<Tdst, V> o;
+    for (int j = 0; j < V; ++j) sm[w - 1][lane].v[j] = acc[j];
+  }
+  __syncthreads();
+  if (w == 0 && col_ok) {
+    Vec o;
 #pragma unroll
-    for (int j = 0; j < V; ++j) o.v[j] = md_cast<Tdst>(acc[q][j]);
-    reinterpret_cast<MdVec<Tdst, V> *>(d)[threadIdx.x + q * MD_BLOCK] = o;
+    for (int j = 0; j < V; ++j) {
+      Tacc v = acc[j];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v = R::combine(v, sm[k][lane].v[j]);
+      o.v[j] = v;
+    }
+    *reinterpret_cast<Vec *>(out + col) = o;
   }
 }
-
-#include "md_cols_merge.h"
 
 // ---------------------------------------------------------------- generic ------
 template <class R, class Tacc, class To>
@@ -516,34 +579,30 @@ struct HipExec {
         const bool vec_ok = pl.nk == 1 && pl.nr == 1 && pl.ko[0] == 1 && x->dtype == md_dtype_of<Tacc>::value &&
                             (n_out % V) == 0 && (pl.rx[0] % V) == 0 && ((uintptr_t)x->data & 15) == 0 &&
                             ((uintptr_t)out->data & 15) == 0 && n_red >= 16;
-        static const int sweep_mode = [] { const char *e = getenv("MDHIP_COLS_SWEEP"); return e ? atoi(e) : 1; }();
-        const int64_t qv = n_out / (MD_BLOCK * V);
-        // (one long block per CU measured best: 4.9 TB/s at 8192 x 4096 f32 against 4.0 with two and 3.8 for the
-        // tiled kernel below; f64 / integer max and min keep the tiled kernel — their compare chain wants more waves per CU)
+        static const int sweep_mode = [] { const char *e = getenv("MDHIP_COLS_SWEEP"); return e ? atoi(e) : 1; }();  // 0: the tiled kernel below (A/B)
+        static const int nb_force = [] { const char *e = getenv("MDHIP_COLS_NB"); return e ? atoi(e) : 0; }();
+        // (f64 / integer max and min keep the tiled kernel — their compare chain wants more waves per CU)
         constexpr bool cheap = md_same<R, RSum>::value || md_same<R, RProd>::value ||
                                ((md_same<R, RMax>::value || md_same<R, RMin>::value) && md_same<Tacc, float>::value);
-        if (cheap && vec_ok && sweep_mode && n_out == qv * MD_BLOCK * V && (qv == 1 || qv == 2 || qv == 4 || qv == 8) && n_red >= 512) {
-          int64_t nblk = sweep_mode > 1 && sweep_mode <= 256 ? sweep_mode : MD_NUM_CUS;  // (the merge pass takes <= 256 partial rows)
-          if (nblk > n_red / 6) nblk = n_red / 6;
-          const int64_t chunk = ceil_div(n_red, nblk);
-          nblk = ceil_div(n_red, chunk);
+        constexpr int RB = 8;
+        const int64_t NS = ceil_div(n_out, 64 * V);
+        // one block per CU (two per CU ran 15 % slower, half a block per CU 20 %: profiles/r3_reduce_lab.txt); <= 64 bands: the
+        // last block of a strip holds all its partial rows in registers
+        int64_t NB = nb_force > 0 ? nb_force : (NS >= MD_NUM_CUS ? 1 : MD_NUM_CUS / NS);
+        if (NB > 64) NB = 64;
+        if (NB > n_red / (4 * RB)) NB = n_red / (4 * RB);
+        if (NB < 1) NB = 1;
+        if (cheap && vec_ok && sweep_mode && n_red >= 512 && NS * NB >= MD_NUM_CUS / 4 && NS * NB < (1ll << 31) &&
+            (NB == 1 || NS * MD_TICKET_PAD <= MD_TICKET_WORDS)) {
           void *partial = nullptr;
-          MD_TRY(mdhip_alloc((size_t)(nblk * n_out) * sizeof(Tacc), &partial));
+          if (NB > 1) MD_TRY(mdhip_alloc((size_t)(NB * n_out) * sizeof(Tacc), &partial));
           const Tacc *xp = (const Tacc *)x->data;
-          const bool nt = n_red * n_out * (int64_t)sizeof(Tacc) > ((int64_t)320 << 20);
-#define MD_SWEEP(QQ)                                                                                                            \
-  if (nt) k_reduce_cols_sweep<R, Tacc, Tacc, QQ, false, true><<<(unsigned)nblk, MD_BLOCK, 0, st>>>(xp, n_out, n_red, pl.rx[0], chunk, (Tacc *)partial); \
-  else k_reduce_cols_sweep<R, Tacc, Tacc, QQ, false, false><<<(unsigned)nblk, MD_BLOCK, 0, st>>>(xp, n_out, n_red, pl.rx[0], chunk, (Tacc *)partial)
-          switch (qv) {
-            case 1: MD_SWEEP(1); break;
-            case 2: MD_SWEEP(2); break;
-            case 4: MD_SWEEP(4); break;
-            default: MD_SWEEP(8); break;
-          }
-#undef MD_SWEEP
-          k_reduce_cols_merge<R, Tacc, To><<<(unsigned)ceil_div(n_out, 64), 1024, 0, st>>>((const Tacc *)partial, n_out, nblk, (To *)out->data);  // nblk <= 256
-          int rc = MD_LAUNCH_CHECK("reduce(cols,sweep)");
-          mdhip_free(partial);
+          if (n_red * n_out * (int64_t)sizeof(Tacc) > ((int64_t)320 << 20))
+            k_reduce_cols_strips<R, Tacc, RB, true><<<(unsigned)(NS * NB), MD_BLOCK, 0, st>>>(xp, n_out, n_red, pl.rx[0], (int)NS, (int)NB, (Tacc *)partial, md_tickets(), (Tacc *)out->data);
+          else
+            k_reduce_cols_strips<R, Tacc, RB, false><<<(unsigned)(NS * NB), MD_BLOCK, 0, st>>>(xp, n_out, n_red, pl.rx[0], (int)NS, (int)NB, (Tacc *)partial, md_tickets(), (Tacc *)out->data);
+          int rc = MD_LAUNCH_CHECK("reduce(cols,strips)");
+          if (partial) mdhip_free(partial);  // stream-ordered: the next user of this block runs after the kernel
           return rc;
         }
         if (vec_ok) {
@@ -597,17 +656,27 @@ struct HipExec {
       if (splits > max_splits) splits = max_splits;
       if (splits < 1) splits = 1;
       if (splits == 1) {
-        k_reduce_rows<R, Tacc, To, true><<<(unsigned)n_out, MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, 1, (To *)out->data);
+        k_reduce_rows<R, Tacc, To, 0><<<(unsigned)n_out, MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, 1, (To *)out->data, nullptr, nullptr);
         return MD_LAUNCH_CHECK("reduce(rows)");
       }
       void *partial = nullptr;
       MD_TRY(mdhip_alloc((size_t)(splits * n_out) * sizeof(Tacc), &partial));
-      if (n_red * n_out * (int64_t)sizeof(Tacc) > ((int64_t)320 << 20))
-        k_reduce_rows<R, Tacc, Tacc, false, true><<<(unsigned)(n_out * splits), MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, splits, (Tacc *)partial);
-      else
-        k_reduce_rows<R, Tacc, Tacc, false><<<(unsigned)(n_out * splits), MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, splits, (Tacc *)partial);
+      const bool nt = n_red * n_out * (int64_t)sizeof(Tacc) > ((int64_t)320 << 20);
+      int rc;
+      if constexpr (sizeof(Tacc) >= 4) {
+        static const bool ticket_on = [] { const char *e = getenv("MDHIP_ROWS_TICKET"); return !(e && e[0] == '0'); }();  // 0: two launches (A/B)
+        if (ticket_on && n_out * (splits >= 64 ? MD_TICKET2_WORDS : MD_TICKET_PAD) <= MD_TICKET_WORDS) {
+          if (nt) k_reduce_rows<R, Tacc, To, 2, true><<<(unsigned)(n_out * splits), MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, splits, (To *)out->data, (Tacc *)partial, md_tickets());
+          else k_reduce_rows<R, Tacc, To, 2><<<(unsigned)(n_out * splits), MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, splits, (To *)out->data, (Tacc *)partial, md_tickets());
+          rc = MD_LAUNCH_CHECK("reduce(rows,ticket)");
+          mdhip_free(partial);
+          return rc;
+        }
+      }
+      if (nt) k_reduce_rows<R, Tacc, Tacc, 1, true><<<(unsigned)(n_out * splits), MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, splits, (Tacc *)partial, nullptr, nullptr);
+      else k_reduce_rows<R, Tacc, Tacc, 1><<<(unsigned)(n_out * splits), MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, splits, (Tacc *)partial, nullptr, nullptr);
       k_finish_rows<R, Tacc, To><<<(unsigned)n_out, MD_BLOCK, 0, st>>>(pl, (const Tacc *)partial, splits, (To *)out->data);
-      int rc = MD_LAUNCH_CHECK("reduce(rows,split)");
+      rc = MD_LAUNCH_CHECK("reduce(rows,split)");
       mdhip_free(partial);
       return rc;
     }

@@ -36,6 +36,7 @@ struct State {
   std::mutex mu;
   int device = -1;
   hipStream_t stream = nullptr;
+  unsigned *tickets = nullptr;                       // md_ticket.h
   std::map<size_t, std::vector<void *>> free_lists;  // rounded size -> blocks
   std::unordered_map<void *, size_t> live;           // ptr -> rounded size
   std::unordered_map<void *, Graph *> owner;         // blocks reserved for a graph (live or privately cached)
@@ -66,6 +67,7 @@ int release_cache_locked(State &s) {
 }  // namespace
 
 hipStream_t md_stream() { return S().stream; }
+unsigned *md_tickets() { return S().tickets; }
 
 // events to attach to the next GEMM kernel (mdhip_event_attach_next)
 static thread_local hipEvent_t t_prof_start = nullptr, t_prof_stop = nullptr;
@@ -101,6 +103,9 @@ int mdhip_init(int device) {
   MD_TRY(md_hip_check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties"));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return md_fail(MDHIP_ERUNTIME, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+  // counters of the single-launch split reductions (md_ticket.h): zero now, and zero again after every launch that uses them
+  MD_TRY(md_hip_check(hipMalloc((void **)&s.tickets, MD_TICKET_WORDS * sizeof(unsigned)), "hipMalloc(tickets)"));
+  MD_TRY(md_hip_check(hipMemset(s.tickets, 0, MD_TICKET_WORDS * sizeof(unsigned)), "hipMemset(tickets)"));
   MD_TRY(md_hip_check(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate"));
   s.device = device;
   return MDHIP_OK;

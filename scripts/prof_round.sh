@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence for profiles/: rocprofv3 kernel stats of bench.py per workload and mode, and HBM traffic
 # (separate --pmc passes for FETCH_SIZE and WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes).
-# usage: prof_round.sh TAG   -> gpurun_out/TAG/{r2_*_kernel_stats.csv, r2_pmc_*.csv, r2_bench_*.json}
+# usage: prof_round.sh TAG   -> gpurun_out/TAG/{${RTAG:-r3}_*_kernel_stats.csv, ${RTAG:-r3}_pmc_*.csv, ${RTAG:-r3}_bench_*.json}
 set -e
 tag=${1:-r2prof}
 out=gpurun_out/$tag
@@ -10,8 +10,8 @@ export TMPDIR=/tmp
 run() {  # name, bench flags
   name=$1; shift
   d=$out/ks_$name
-  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --no-secondary --no-cpu-baseline --steps 20 --warmup 3 "$@" > $out/r2_bench_${name}_under_rocprof.log 2>&1
-  cp $(find $d -name '*kernel_stats.csv' | head -1) $out/r2_${name}_kernel_stats.csv
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --no-secondary --no-cpu-baseline --steps 20 --warmup 3 "$@" > $out/${RTAG:-r3}_bench_${name}_under_rocprof.log 2>&1
+  cp $(find $d -name '*kernel_stats.csv' | head -1) $out/${RTAG:-r3}_${name}_kernel_stats.csv
   rm -rf $d
   echo "kernel stats $name done"
 }
@@ -20,7 +20,7 @@ pmc() {  # name, bench flags: two passes
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d $out/pmc_${name}_$c -- python3 bench.py --no-secondary --no-cpu-baseline --steps 3 --warmup 1 "$@" > $out/pmc_${name}_$c.log 2>&1
   done
-  python3 scripts/pmc_summary.py $out/r2_pmc_$name.csv $out/pmc_${name}_FETCH_SIZE $out/pmc_${name}_WRITE_SIZE
+  python3 scripts/pmc_summary.py $out/${RTAG:-r3}_pmc_$name.csv $out/pmc_${name}_FETCH_SIZE $out/pmc_${name}_WRITE_SIZE
   rm -rf $out/pmc_${name}_FETCH_SIZE $out/pmc_${name}_WRITE_SIZE
   echo "pmc $name done"
 }
@@ -35,5 +35,5 @@ pmc cfg4_lazy --workload cfg4 --lazy
 pmc cfg3_lazy --workload cfg3 --lazy
 pmc cfg3 --workload cfg3
 pmc cfg2 --workload cfg2
-python3 bench.py > $out/r2_bench_default.json 2> $out/r2_bench_default.err
+python3 bench.py > $out/${RTAG:-r3}_bench_default.json 2> $out/${RTAG:-r3}_bench_default.err
 echo all done
