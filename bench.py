@@ -73,6 +73,7 @@ class KernelTimer:
         self.only = None  # when set: bracket these tags only (every bracket costs ~4 us of stream time)
         self.attach = os.environ.get("MDHIP_BENCH_ATTACH", "1") != "0"   # GEMM calls: kernel-attached events instead of markers
         self.attach_tags = ("gemm_exec",)   # lazy mode: the call that materialises a deferred product
+        self.marker_tags = set()            # tags whose call launched no attachable kernel: bracketed by marker events instead
 
     def _event(self):
         if self.pool:
@@ -90,15 +91,18 @@ class KernelTimer:
             if self.only is not None and name not in self.only and not (name.startswith("matmul") and "matmul" in self.only):
                 return fn(*a, **kw)
             e0, e1 = self._event(), self._event()
-            if self.attach and (name.startswith("matmul") or name in self.attach_tags):
-                # the GEMM kernel this call launches carries the two timestamps itself (mdhip_event_attach_next): no marker
-                # packets in the stream, which cost ~5 us each between two kernels (1 % of the cfg2 sweep for its three GEMMs)
+            if self.attach and name not in self.marker_tags:
+                # the main kernel this call launches carries the two timestamps itself (mdhip_event_attach_next -> MD_LAUNCH /
+                # the GEMM launchers / the fused-kernel launcher): the kernel's own duration, no marker packets in the stream
+                # (a marker pair costs ~4 us of stream time and read 5-15 % low on the 25-50 us streaming kernels)
                 self.lib.event_attach_next(e0, e1)
                 out = fn(*a, **kw)
                 pending = self.C.c_int(0)
                 self.lib.event_attach_cancel(self.C.byref(pending))
-                if pending.value:          # the call launched no matrix-core kernel (deferred product, other dtype): nothing recorded
-                    self.pool += [e0, e1]
+                if pending.value:          # the call launched no attachable kernel (deferred product, generic path): nothing recorded;
+                    self.pool += [e0, e1]  # bracket this tag with markers from now on — except the products, which may just be deferred
+                    if not (name.startswith("matmul") or name in self.attach_tags):
+                        self.marker_tags.add(name)
                 else:
                     self.used.append((name, e0, e1))
                 return out
@@ -174,7 +178,7 @@ def cpu_baseline(workload, size):
             kw["batch"] = size
         sample = "full cfg4 sweep (global batch on one host), best of 3 after 1 warm-up"
         reps = 3
-    _, step = workloads.MAKERS[workload](md, **kw)
+    state, step = workloads.MAKERS[workload](md, **kw)
     step()
     best = float("inf")
     for _ in range(reps):
@@ -186,10 +190,29 @@ def cpu_baseline(workload, size):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # the oracle's gradients of that sweep (same seeds as the device run): the metric's second half, "grad L-inf vs NumPy"
+    grads = {name: np.asarray(state[name].grad.as_numpy()) for name in GRAD_NAMES[workload]}
     return {
         "value": scale / best, "unit": "passes/s", "cores": cores, "kind": "port",
         "sample": sample + f"; numpy {np.__version__}; GEMM threads = all cores, ufuncs single-threaded",
-    }
+    }, grads
+
+
+GRAD_NAMES = {"cfg2": ("A", "B"), "cfg3": ("x", "y"), "cfg4": ("W", "b"), "cfg5": ("A", "B")}
+
+
+def grad_linf_rel(device_grads, oracle_grads):
+    """norm-wise max|g_hip - g_np| / max|g_np| per gradient (the oracle may hold a prefix of the device's
+    vector: cfg3's CPU sample is a tenth of the workload, and element i of its gradients depends on x[i], y[i] alone)."""
+    out = {}
+    for name, ref in oracle_grads.items():
+        dev = device_grads.get(name)
+        if dev is None:
+            continue
+        d = dev.reshape(-1)[: ref.size] if dev.size != ref.size else dev.reshape(-1)
+        r = ref.reshape(-1).astype(np.float64)
+        out[name] = float(np.max(np.abs(d.astype(np.float64) - r)) / max(np.max(np.abs(r)), 1e-300))
+    return out
 
 
 PREROLL = {"cfg2": 12, "cfg3": 20, "cfg4": 10, "cfg5": 40}
@@ -235,10 +258,10 @@ def rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc):
         gemm_kernel = "k_gemm_f32_kc_glds (NN, NT) / k_gemm_f32_tn_glds (TN)" if dma else "k_gemm_f32_mfma"
         if workload == "cfg4" and lazy:
             # lazy mode defers the products: the forward GEMM runs inside the loss reduction with the bias / relu / sum
-            # epilogue (bracket "sum_all", incl. its 1-block finish), the weight-gradient GEMM when W.grad is materialised
+            # epilogue (bracket "sum_all": one launch, the last block sums the per-block relu sums), the weight-gradient GEMM when W.grad is materialised
             durs = kernel_ms.get("sum_all", []) + kernel_ms.get("gemm_exec", [])
-            gemm_kernel = ("k_gemm_f32_kc_glds (NN with the bias + relu-sum + mask epilogue, + finish) and k_gemm_f32_tn_glds (TN)" if dma
-                           else "k_gemm_f32_mfma (NN with the bias + relu-sum + mask epilogue, + finish) and k_gemm_f32_mfma (TN)")
+            gemm_kernel = ("k_gemm_f32_kc_glds (NN with the bias + relu-sum + mask epilogue) and k_gemm_f32_tn_glds (TN)" if dma
+                           else "k_gemm_f32_mfma (NN with the bias + relu-sum + mask epilogue) and k_gemm_f32_mfma (TN)")
         elif lazy:
             durs = kernel_ms.get("gemm_exec", [])
         elif workload == "cfg4":
@@ -267,12 +290,12 @@ def rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc):
                         tail[tag] = _hbm(name, nbytes, _mean(kernel_ms[tag]))
                 if "multiply" in tail and "sum_cols" in tail:
                     ms = tail["multiply"]["avg_launch_ms"] + tail["sum_cols"]["avg_launch_ms"]
-                    tail["backward_pair"] = _hbm("elementwise + reduce-to-shape backward: mask product, then column sum (2 + 2 launches)",
+                    tail["backward_pair"] = _hbm("elementwise + reduce-to-shape backward: mask product (k_ew_fast), then column sum (k_reduce_cols_strips): one launch each",
                                                  9 * e + 4 * cols, ms, note="north_star's >= 60 % HBM target is on this pair")
             else:
                 # the forward tail (bias add, relu, mask, loss) lives in the NN GEMM's epilogue: no kernel of its own
                 if kernel_ms.get("materialize"):
-                    tail["backward_pair"] = _hbm("k_fused_evalcols: g*mask written AND column-summed in one pass over the mask (+ merge)",
+                    tail["backward_pair"] = _hbm("k_fused_evalcols: g*mask written AND column-summed in one pass over the mask, ONE launch (the last block of a strip merges its partial rows)",
                                                  5 * e + 8 * cols, _mean(kernel_ms["materialize"]),
                                                  eager_algorithmic_bytes=9 * e + 4 * cols,
                                                  note="fused bytes: the bool mask read once, g*mask written once; the eager figure is not mixed in")
@@ -287,10 +310,10 @@ def rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc):
         main = {"bound": "hbm", "kernel": "k_fused_redall + k_fused_eval2 (run-time specialised), whole sweep",
                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
                 "fused_algorithmic_bytes_per_sweep": fused_bytes, "eager_algorithmic_bytes_per_sweep": state["bytes"],
-                "note": "achieved = fused bytes / whole-sweep wall time (3 launches incl. the reduction's finish); the eager figure (100N bytes) is not mixed in"}
+                "note": "achieved = fused bytes / whole-sweep wall time (2 launches); the eager figure (100N bytes) is not mixed in"}
         k = {}
         if kernel_ms.get("sum_all"):
-            k["loss_pass"] = _hbm("k_fused_redall: sum((sin(x)*y)**2), reads x and y (+ finish)", 8 * n, _mean(kernel_ms["sum_all"]))
+            k["loss_pass"] = _hbm("k_fused_redall: sum((sin(x)*y)**2), reads x and y; one launch (the last block sums the block partials)", 8 * n, _mean(kernel_ms["sum_all"]))
         if kernel_ms.get("materialize_many"):
             k["gradient_pass"] = _hbm("k_fused_eval2: x.grad and y.grad in one pass, one sincos per element", 16 * n, _mean(kernel_ms["materialize_many"]))
         detail["fused_kernels"] = k
@@ -310,6 +333,43 @@ def rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc):
                                  "GB/s": state["bytes"] * steps / (tot_ms * 1e-3) / 1e9,
                                  "frac": state["bytes"] * steps / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS})
     return main, detail
+
+
+def compact_secondary(secondary):
+    """Per-config roofline fractions in a few numbers each: the driver keeps `roofline` whole and only the NAMES of other
+    top-level keys. frac = share of 157.3 TFLOP/s (GEMM kernels) or of 8 TB/s (streaming kernels, algorithmic bytes of
+    SURVEY 8d); kernel durations are the kernels' own dispatch timestamps (event-attached), ms = average per launch."""
+    def pick(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or d.get(k) is None:
+                return None
+            d = d[k]
+        return d
+
+    def kern(r):
+        return None if r is None else {"frac": r.get("frac"), "ms": r.get("avg_launch_ms"), "bytes": r.get("algorithmic_bytes_per_launch")}
+
+    out = {}
+    for name, r in secondary.items():
+        if "error" in r:
+            out[name] = {"error": r["error"]}
+            continue
+        c = {"passes_per_s": r["value"], "ms_per_step": r["ms_per_step"], "bound": pick(r, "roofline", "bound"),
+             "frac": pick(r, "roofline", "frac"), "achieved": pick(r, "roofline", "achieved"), "unit": pick(r, "roofline", "unit")}
+        tail = pick(r, "kernels", "hbm_tail") or {}
+        for key, short in (("backward_pair", "pair"), ("sum_all", "loss_sum"), ("sum_cols", "colsum"), ("multiply", "maskprod"),
+                           ("add", "bias_add"), ("greater", "greater"), ("where", "where")):
+            if key in tail:
+                c[short] = kern(tail[key])
+        fused = pick(r, "kernels", "fused_kernels") or {}
+        for key in ("loss_pass", "gradient_pass"):
+            if key in fused:
+                c[key] = kern(fused[key])
+        ws = pick(r, "roofline", "whole_sweep")
+        if ws:
+            c["whole_sweep_frac"] = ws.get("frac")
+        out[name] = c
+    return out
 
 
 def main():
@@ -418,7 +478,7 @@ def main():
                 kind = "rccl-torch"
         return comm, kind
 
-    def run(workload, lazy, steps, warmup, graph=False, size=0, keep=None, solo=False):
+    def run(workload, lazy, steps, warmup, graph=False, size=0, keep=None, solo=False, want_grads=False):
         """One workload: pre-roll, W warm-up sweeps, K timed sweeps between barriers, max over ranks.
         `keep`: dict carrying (state, step) between the eager and the lazy run of one workload.
         `solo` (N > 1 jobs): every rank runs the UN-sharded workload on its own GPU with no collective, and the time is the
@@ -570,6 +630,8 @@ def main():
         }
         if workload == "cfg4":
             res["tensors_per_s"] = (size or 8192) * value  # batch rows through forward+backward per second
+        if want_grads:   # the last sweep's gradients, copied to the host AFTER the timed region (the L-inf check against the oracle)
+            res["_grads"] = {name: np.asarray(state[name].grad.as_numpy()) for name in GRAD_NAMES[workload]}
         sync.close()
         if comm is not None:
             comm.close()
@@ -578,7 +640,9 @@ def main():
         nd.set_lazy(prev_lazy)
         return res
 
-    head = run(args.workload, args.lazy, args.steps, args.warmup, graph=args.graph, size=args.size)
+    check_grads = rank == 0 and world == 1 and not args.no_cpu_baseline
+    head = run(args.workload, args.lazy, args.steps, args.warmup, graph=args.graph, size=args.size, want_grads=check_grads)
+    head_grads = head.pop("_grads", None)
     event_overhead_ms = timer.empty_bracket_ms()
     # N > 1: the headline is the batch-sharded cfg4 sweep, the driver's N = 1 run is cfg2 — so the same job also times the
     # UN-sharded sweep of the headline workload on one GPU (every rank on its own card, no collective; rank 0's figure)
@@ -595,9 +659,12 @@ def main():
         gc.collect()
         lib.empty_cache()
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.workload, args.size)
+    cpu = linf = None
+    if check_grads:
+        cpu, oracle_grads = cpu_baseline(args.workload, args.size)
+        if head_grads is not None:
+            linf = grad_linf_rel(head_grads, oracle_grads)
+        head_grads = oracle_grads = None
 
     # ---- the other BASELINE configs, same process, after the headline's timed region -------------------
     secondary = None
@@ -641,6 +708,11 @@ def main():
             "roofline": head["roofline"], "cpu_baseline": cpu,
             "single_sweep_ms": head["single_sweep_ms"],
         }
+        # the metric's second half: gradients of the headline sweep against the NumPy engine on the same seeds
+        # (norm-wise; bar 1e-5 for fp32). None when the CPU leg is skipped (N > 1, --no-cpu-baseline).
+        line["grad_linf_rel"] = linf
+        if secondary and line["roofline"] is not None:
+            line["roofline"]["secondary"] = compact_secondary(secondary)
         if "tensors_per_s" in head:
             line["tensors_per_s"] = head["tensors_per_s"]
         if solo is not None:

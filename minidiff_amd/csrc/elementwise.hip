@@ -418,7 +418,7 @@ template <class Body, int U> static int launch_fast(const Body &body, const Fast
   fg.inner = g.inner;
   fg.dq = nv > 0 ? stride / nv : 0;
   fg.dr = nv > 0 ? stride % nv : 0;
-  k_ew_fast<Body, U><<<grid, MD_BLOCK, 0, md_stream()>>>(body, fg);
+  MD_LAUNCH((k_ew_fast<Body, U>), grid, MD_BLOCK, body, fg);
   return MD_LAUNCH_CHECK(what);
 }
 

@@ -1,6 +1,7 @@
 // md_hip.h — device-side helpers shared by the .hip translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 
 #include "md_dispatch.h"
@@ -9,10 +10,20 @@
 
 hipStream_t md_stream();
 unsigned *md_tickets();                                   // MD_TICKET_WORDS zeroed counters (md_ticket.h)
-bool md_prof_take(hipEvent_t *start, hipEvent_t *stop);   // bench timing: events for the next GEMM kernel, if any were attached
+bool md_prof_take(hipEvent_t *start, hipEvent_t *stop);   // bench timing: events for the next main kernel (MD_LAUNCH, the GEMM launchers), if any were attached
 int md_hip_check(hipError_t e, const char *what);
 
 #define MD_LAUNCH_CHECK(name) md_hip_check(hipGetLastError(), name)
+
+// Launch on the library's stream. With events attached (mdhip_event_attach_next: bench.py) the dispatch ITSELF carries the
+// start / stop timestamps — the kernel's own duration, no marker packets around it (a marker pair costs ~4 us of stream
+// time and reads 5-15 % low on a 25-us streaming kernel). Kernel names with template commas go in parentheses.
+#define MD_LAUNCH(kernel, grid, block, ...)                                                                            \
+  do {                                                                                                                 \
+    hipEvent_t md_e0_, md_e1_;                                                                                         \
+    if (md_prof_take(&md_e0_, &md_e1_)) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, md_stream(), md_e0_, md_e1_, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, md_stream(), __VA_ARGS__);                             \
+  } while (0)
 
 // MI355X: 256 CUs. Streaming kernels cap the grid and stride (guide §6 G11).
 constexpr int MD_NUM_CUS = 256;

@@ -129,6 +129,46 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows(MdRedPlan pl, const vo
   }
 }
 
+// Full reduction of a contiguous array of the accumulator's own type (the loss `sum` of the BASELINE graphs): the rows
+// kernel above without its plan — a lane strides the 16-B vectors of the whole grid, two in flight — and the ticket finish
+// (md_ticket.h, two-level: ~1000 blocks arrive). 24.0 -> 22.5 us on cfg4's 128 MiB against the general kernel: the plan's
+// 400-byte argument block and per-thread offset arithmetic cost 1.5 us of a 20-us stream (profiles/r3_reduce_lab.txt).
+template <class R, class Tacc, class Tdst, bool NT>
+__global__ void __launch_bounds__(MD_BLOCK) k_reduce_all(const Tacc *__restrict__ x, int64_t n, Tacc *partial, unsigned *tickets, Tdst *out) {
+  constexpr int V = 16 / sizeof(Tacc);
+  typedef MdVec<Tacc, V> Vec;
+  __shared__ Tacc smem[MD_BLOCK / 64];
+  __shared__ unsigned last_flag;
+  const int64_t gs = (int64_t)gridDim.x * MD_BLOCK, gid = (int64_t)blockIdx.x * MD_BLOCK + threadIdx.x;
+  const int64_t nvec = n / V;  // (x is 16-B aligned: checked on the host)
+  const Vec *pv = reinterpret_cast<const Vec *>(x);
+  Tacc a2[V], a3[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { a2[j] = R::template identity<Tacc>(); a3[j] = a2[j]; }
+  int64_t i = gid;
+  for (; i + gs < nvec; i += 2 * gs) {
+    const Vec t = md_ld_once<NT>(pv + i), u = md_ld_once<NT>(pv + i + gs);
+#pragma unroll
+    for (int j = 0; j < V; ++j) { a2[j] = R::combine(a2[j], t.v[j]); a3[j] = R::combine(a3[j], u.v[j]); }
+  }
+  if (i < nvec) {
+    const Vec t = pv[i];
+#pragma unroll
+    for (int j = 0; j < V; ++j) a2[j] = R::combine(a2[j], t.v[j]);
+  }
+  Tacc acc = R::template identity<Tacc>();
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc = R::combine(acc, R::combine(a2[j], a3[j]));
+  if (nvec * V + gid < n) acc = R::combine(acc, x[nvec * V + gid]);  // the up-to-(V-1) elements behind the last whole vector
+  acc = md_block_reduce<R>(acc, smem);
+  if (threadIdx.x == 0) md_st_sc1(partial + blockIdx.x, acc);
+  const bool last = gridDim.x >= 64 ? md_ticket_last2(tickets, blockIdx.x, gridDim.x, &last_flag) : md_ticket_last(tickets, gridDim.x, &last_flag);
+  if (!last) return;
+  Tacc a = md_fold_partials<R>(partial, gridDim.x);
+  a = md_block_reduce<R>(a, smem);
+  if (threadIdx.x == 0) out[0] = md_cast<Tdst>(a);
+}
+
 template <class R, class Tacc, class To>
 __global__ void __launch_bounds__(MD_BLOCK) k_finish_rows(MdRedPlan pl, const Tacc *partial, int64_t splits, To *out) {
   __shared__ Tacc smem[MD_BLOCK / 64];
@@ -598,9 +638,9 @@ struct HipExec {
           if (NB > 1) MD_TRY(mdhip_alloc((size_t)(NB * n_out) * sizeof(Tacc), &partial));
           const Tacc *xp = (const Tacc *)x->data;
           if (n_red * n_out * (int64_t)sizeof(Tacc) > ((int64_t)320 << 20))
-            k_reduce_cols_strips<R, Tacc, RB, true><<<(unsigned)(NS * NB), MD_BLOCK, 0, st>>>(xp, n_out, n_red, pl.rx[0], (int)NS, (int)NB, (Tacc *)partial, md_tickets(), (Tacc *)out->data);
+            MD_LAUNCH((k_reduce_cols_strips<R, Tacc, RB, true>), (unsigned)(NS * NB), MD_BLOCK, xp, n_out, n_red, pl.rx[0], (int)NS, (int)NB, (Tacc *)partial, md_tickets(), (Tacc *)out->data);
           else
-            k_reduce_cols_strips<R, Tacc, RB, false><<<(unsigned)(NS * NB), MD_BLOCK, 0, st>>>(xp, n_out, n_red, pl.rx[0], (int)NS, (int)NB, (Tacc *)partial, md_tickets(), (Tacc *)out->data);
+            MD_LAUNCH((k_reduce_cols_strips<R, Tacc, RB, false>), (unsigned)(NS * NB), MD_BLOCK, xp, n_out, n_red, pl.rx[0], (int)NS, (int)NB, (Tacc *)partial, md_tickets(), (Tacc *)out->data);
           int rc = MD_LAUNCH_CHECK("reduce(cols,strips)");
           if (partial) mdhip_free(partial);  // stream-ordered: the next user of this block runs after the kernel
           return rc;
@@ -664,10 +704,18 @@ struct HipExec {
       const bool nt = n_red * n_out * (int64_t)sizeof(Tacc) > ((int64_t)320 << 20);
       int rc;
       if constexpr (sizeof(Tacc) >= 4) {
+        static const bool all_on = [] { const char *e = getenv("MDHIP_REDUCE_ALL"); return !(e && e[0] == '0'); }();  // 0: the general rows kernel (A/B)
+        if (all_on && n_out == 1 && pl.nr == 1 && pl.rx[0] == 1 && x->dtype == md_dtype_of<Tacc>::value && ((uintptr_t)x->data & 15) == 0) {
+          if (nt) MD_LAUNCH((k_reduce_all<R, Tacc, To, true>), (unsigned)splits, MD_BLOCK, (const Tacc *)x->data, n_red, (Tacc *)partial, md_tickets(), (To *)out->data);
+          else MD_LAUNCH((k_reduce_all<R, Tacc, To, false>), (unsigned)splits, MD_BLOCK, (const Tacc *)x->data, n_red, (Tacc *)partial, md_tickets(), (To *)out->data);
+          rc = MD_LAUNCH_CHECK("reduce(all)");
+          mdhip_free(partial);
+          return rc;
+        }
         static const bool ticket_on = [] { const char *e = getenv("MDHIP_ROWS_TICKET"); return !(e && e[0] == '0'); }();  // 0: two launches (A/B)
         if (ticket_on && n_out * (splits >= 64 ? MD_TICKET2_WORDS : MD_TICKET_PAD) <= MD_TICKET_WORDS) {
-          if (nt) k_reduce_rows<R, Tacc, To, 2, true><<<(unsigned)(n_out * splits), MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, splits, (To *)out->data, (Tacc *)partial, md_tickets());
-          else k_reduce_rows<R, Tacc, To, 2><<<(unsigned)(n_out * splits), MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, splits, (To *)out->data, (Tacc *)partial, md_tickets());
+          if (nt) MD_LAUNCH((k_reduce_rows<R, Tacc, To, 2, true>), (unsigned)(n_out * splits), MD_BLOCK, pl, x->data, x->dtype, splits, (To *)out->data, (Tacc *)partial, md_tickets());
+          else MD_LAUNCH((k_reduce_rows<R, Tacc, To, 2>), (unsigned)(n_out * splits), MD_BLOCK, pl, x->data, x->dtype, splits, (To *)out->data, (Tacc *)partial, md_tickets());
           rc = MD_LAUNCH_CHECK("reduce(rows,ticket)");
           mdhip_free(partial);
           return rc;

@@ -339,6 +339,93 @@ __global__ void __launch_bounds__(256) k_sum_all(const float *__restrict__ x0, i
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+
+// software-pipelined full sum: two batches of U grid-strided vectors in flight per lane
+template <int U, int TICKET, int GRID>
+__global__ void __launch_bounds__(256) k_sum_pipe(const float *__restrict__ x, int64_t nvec, float *partial, unsigned *ticket, float *out) {
+  __shared__ float smem[4];
+  __shared__ unsigned flag;
+  const int64_t gs = (int64_t)GRID * 256;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t ntrip = nvec / (gs * U);   // whole batches (every lane has all U vectors)
+  f4 a[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) a[u] = (f4){0.f, 0.f, 0.f, 0.f};
+  f4 t[2][U];
+  auto load = [&](int buf, int64_t bt) {
+    const int64_t b = bt < ntrip ? bt : ntrip - 1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) t[buf][u] = ld16(x + 4 * (i0 + (b * U + u) * gs), 0);
+  };
+  auto add = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] += t[buf][u];
+  };
+  if (ntrip > 0) {
+    load(0, 0);
+    int64_t bt = 0;
+    for (; bt + 1 < ntrip; bt += 2) {
+      load(1, bt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      add(0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(0, bt + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      add(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (bt < ntrip) add(0);
+  }
+  for (int64_t i = i0 + ntrip * U * gs; i < nvec; i += gs) a[0] += ld16(x + 4 * i, 0);
+  float acc = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) acc += (a[u].x + a[u].y) + (a[u].z + a[u].w);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) smem[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    if (TICKET) __hip_atomic_store(partial + blockIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else partial[blockIdx.x] = v;
+  }
+  if (!TICKET) return;
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+      unsigned last = 0;
+      const unsigned sh = blockIdx.x & 31;
+      if (__hip_atomic_fetch_add(ticket + 32 * sh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GRID / 32 - 1) {
+        __hip_atomic_store(ticket + 32 * sh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = __hip_atomic_fetch_add(ticket + 32 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 31;
+      }
+      flag = last;
+    }
+    __syncthreads();
+    if (!flag) return;
+    ticket += 32 * 32;
+  }
+  float s = 0.f;
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const unsigned idx = threadIdx.x + 256 * k;
+    v[k] = idx < GRID ? __hip_atomic_load(partial + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += v[k];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+  __syncthreads();
+  if (lane == 0) smem[w] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *out = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_sum_finish(const float *partial, int n, float *out) {
   __shared__ float smem[4];
   float s = 0.f;
@@ -544,16 +631,36 @@ int main(int argc, char **argv) {
       }                                                                                                \
     }                                                                                                  \
   }
+#define SUMPIPE(U, TK, GRID)                                                                           \
+  {                                                                                                    \
+    char label[128];                                                                                   \
+    snprintf(label, sizeof label, "sumpipe<U%d TK%d GRID%d>", U, TK, GRID);                            \
+    for (int it = 0; it < iters; ++it) {                                                               \
+      forward();                                                                                       \
+      k_sum_pipe<U, TK, GRID><<<GRID, 256, 0, st>>>(r, N / 4, partial, tickets + 2048, loss);           \
+      if (!TK) k_sum_finish<<<1, 256, 0, st>>>(partial, GRID, loss);                                   \
+      if (it == 0) {                                                                                   \
+        CK(hipStreamSynchronize(st));                                                                  \
+        float v;                                                                                       \
+        CK(hipMemcpy(&v, loss, 4, hipMemcpyDeviceToHost));                                             \
+        printf("  %-52s rel err %.2e\n", label, fabs(v - ref_loss) / fabs(ref_loss));                 \
+      }                                                                                                \
+    }                                                                                                  \
+  }
   if (want("sum")) {
+    for (int it = 0; it < iters; ++it) { forward(); base_loss(); }
     SUMALL(2, 0, 0, 1024, 0);
     SUMALL(2, 0, 2, 1024, 0);
-    SUMALL(4, 0, 2, 1024, 0);
-    SUMALL(1, 0, 2, 1024, 0);
-    SUMALL(2, 0, 2, 512, 0);
-    SUMALL(4, 0, 2, 512, 0);
-    SUMALL(1, 0, 2, 2048, 0);
-    SUMALL(2, 0, 2, 768, 0);
-    SUMALL(2, 0, 2, 1280, 0);
+    SUMPIPE(2, 0, 1024);
+    SUMPIPE(2, 1, 1024);
+    SUMPIPE(4, 1, 1024);
+    SUMPIPE(4, 1, 512);
+    SUMPIPE(8, 1, 512);
+    SUMPIPE(8, 1, 256);
+    SUMPIPE(4, 1, 256);
+    SUMPIPE(16, 1, 256);
+    SUMPIPE(1, 1, 1024);
+    SUMPIPE(1, 1, 2048);
   }
   // ---- D: the mask product (context: forward + loss sum) ----
 #define MASKP(U, NTST, GRID)                                                       \

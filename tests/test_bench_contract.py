@@ -33,6 +33,10 @@ def test_bench_prints_one_contract_line(lib, on_gpu, workload, extra):
     assert r is None or {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r)
     c = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] == "port" and c["value"] > 0
+    # the metric's second half: gradients of the headline sweep against the NumPy engine, norm-wise (<= 1e-5 for fp32)
+    g = d["grad_linf_rel"]
+    assert set(g) == {"cfg2": {"A", "B"}, "cfg3": {"x", "y"}, "cfg5": {"A", "B"}}[workload]
+    assert all(0.0 <= v <= 1e-5 for v in g.values()), g
 
 
 def test_bench_two_ranks_control_flow_over_gloo(lib, on_gpu):
