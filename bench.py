@@ -74,6 +74,7 @@ class KernelTimer:
         self.attach = os.environ.get("MDHIP_BENCH_ATTACH", "1") != "0"   # GEMM calls: kernel-attached events instead of markers
         self.attach_tags = ("gemm_exec",)   # lazy mode: the call that materialises a deferred product
         self.marker_tags = set()            # tags whose call launched no attachable kernel: bracketed by marker events instead
+        self._open = None                   # (start, stop) of the attach bracket that is open right now (brackets nest)
 
     def _event(self):
         if self.pool:
@@ -95,10 +96,22 @@ class KernelTimer:
                 # the main kernel this call launches carries the two timestamps itself (mdhip_event_attach_next -> MD_LAUNCH /
                 # the GEMM launchers / the fused-kernel launcher): the kernel's own duration, no marker packets in the stream
                 # (a marker pair costs ~4 us of stream time and read 5-15 % low on the 25-50 us streaming kernels)
+                # (brackets nest in lazy mode: materialising a deferred product first materialises its pending operand. The
+                # enclosing bracket's events are set aside while the inner call runs and re-attached behind it, so that they
+                # ride on the enclosing call's OWN kernel and not on the first launch that comes along)
+                outer, outer_pending = self._open, self.C.c_int(0)
+                if outer is not None:
+                    self.lib.event_attach_cancel(self.C.byref(outer_pending))
                 self.lib.event_attach_next(e0, e1)
-                out = fn(*a, **kw)
-                pending = self.C.c_int(0)
-                self.lib.event_attach_cancel(self.C.byref(pending))
+                self._open = (e0, e1)
+                try:
+                    out = fn(*a, **kw)
+                finally:
+                    pending = self.C.c_int(0)
+                    self.lib.event_attach_cancel(self.C.byref(pending))
+                    self._open = outer
+                    if outer is not None and outer_pending.value:
+                        self.lib.event_attach_next(*outer)
                 if pending.value:          # the call launched no attachable kernel (deferred product, generic path): nothing recorded;
                     self.pool += [e0, e1]  # bracket this tag with markers from now on — except the products, which may just be deferred
                     if not (name.startswith("matmul") or name in self.attach_tags):
@@ -520,9 +533,35 @@ def main():
             sweep()
         lib.sync()
         captured = None
-        if graph:
+        # N > 1: the sweep's kernels are short (65-250 us at 8 ranks) and ~7 us of Python dispatch per backend call would sit
+        # between them: replay the sweep as hipGraph SEGMENTS with the collectives between them (graph.SegmentedSweep;
+        # MDHIP_DP_GRAPH=0 keeps the eager sweep). A build that cannot capture (the CPU double) stays eager.
+        segmented = bool(use_dist and comm is not None and sync.active and not graph and os.environ.get("MDHIP_DP_GRAPH", "1") != "0")
+        if segmented:
+            from minidiff_amd.graph import can_capture
+            segmented = can_capture(lib)
+        if segmented:
+            sweep()
+            timer.enabled = True   # per-kernel durations for the roofline come from the eager warm-up sweeps
+            for _ in range(max(warmup, 1)):
+                sweep()
+            lib.sync()
+            timer.enabled = False
+            from minidiff_amd.graph import SegmentedSweep
+            try:
+                captured = SegmentedSweep(sweep, comm)
+                captured.replay()
+                run_one = captured.replay
+            except RuntimeError as e:
+                captured, segmented = None, False
+                if rank == 0:
+                    print(f"[bench] segmented graph capture unavailable ({e}); eager sweeps", file=sys.stderr)
+                run_one = sweep
+        if segmented:
+            pass
+        elif graph:
             if use_dist:
-                raise SystemExit("--graph is a single-GPU mode (the gradient all-reduce is not captured)")
+                raise SystemExit("--graph is a single-GPU mode (N > 1 replays graph segments by default: MDHIP_DP_GRAPH)")
             # single kernels cannot be bracketed inside a replay: the per-kernel durations the roofline
             # needs come from the (eager, identical) warm-up sweeps instead
             sweep()  # cold start (code object load, allocator growth) stays out of the kernel averages
@@ -546,7 +585,7 @@ def main():
                     "cfg4": {"gemm_exec", "sum_all"} if lazy else {"matmul"},
                     "cfg3": set() if lazy else {"multiply"}}[workload]
         timer.only = dominant
-        timer.enabled = not graph and bool(dominant)
+        timer.enabled = not graph and not segmented and bool(dominant)
         t0 = time.perf_counter()
         for _ in range(steps):
             run_one()
@@ -566,7 +605,7 @@ def main():
         # SURVEY 8d also asks for the median and the minimum of single sweeps: ten more sweeps, each synchronised at its
         # end (outside the timed region: a per-sweep sync costs the overlap between consecutive sweeps)
         single = []
-        if not graph:
+        if not graph:   # (eager sweeps also in segmented mode: what one sweep costs with Python dispatch in it)
             for _ in range(10):
                 barrier()
                 t1 = time.perf_counter()
@@ -623,7 +662,8 @@ def main():
             "scaling": scaling,
             "single_sweep_ms": {"median": single[len(single) // 2], "min": single[0], "n": len(single)} if single else None,
             "config": {"workload": describe(workload, n, lazy), "parallelism": f"dp{world}", "lazy_fusion": bool(lazy),
-                       "graph_replay": bool(graph), "collective": comm_kind, "allreduce_bytes": sync.nbytes if use_dist else 0,
+                       "graph_replay": bool(graph) or ({"segments": captured.segments, "collective_calls": captured.calls} if segmented else False),
+                       "collective": comm_kind, "allreduce_bytes": sync.nbytes if use_dist else 0,
                        "allreduce_overlapped_sweeps": sync.overlapped, "allreduce_panels": getattr(sync, "panels", 1),
                        "allreduce_alone_ms": allreduce_ms, "allreduce_busbw_GBps": busbw},
             "roofline": roof, "kernels": detail,

@@ -30,6 +30,7 @@ namespace {
 struct Graph {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  bool empty = false;                                 // a capture that recorded nothing: launching it is a no-op
   std::map<size_t, std::vector<void *>> free_lists;  // private pool
 };
 struct State {
@@ -342,7 +343,11 @@ int mdhip_graph_end(void **graph_out) {
   if (!g) return md_fail(MDHIP_ERUNTIME, "no capture in progress");
   s.capturing = nullptr;
   hipError_t e = hipStreamEndCapture(s.stream, &g->graph);
-  if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e == hipSuccess) {
+    size_t n_nodes = 0;
+    if (g->graph && hipGraphGetNodes(g->graph, nullptr, &n_nodes) == hipSuccess && n_nodes == 0) g->empty = true;  // nothing to launch
+    else e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  }
   if (e != hipSuccess) {
     (void)hipGetLastError();
     // an invalidated capture can leave the stream refusing work ("previous error during capture"):
@@ -376,6 +381,7 @@ int mdhip_graph_end(void **graph_out) {
 
 int mdhip_graph_launch(void *graph) {
   Graph *g = (Graph *)graph;
+  if (g && g->empty) return MDHIP_OK;
   if (!g || !g->exec) return md_fail(MDHIP_EVALUE, "graph_launch: null graph");
   return md_hip_check(hipGraphLaunch(g->exec, md_stream()), "hipGraphLaunch");
 }

@@ -151,15 +151,26 @@ class HostComm:
         pass
 
 
+def auto_panels(K: int, N: int, cap: int = 8) -> int:
+    """Row panels for a K x N weight gradient: as many as leave every panel's GEMM a FULL round of 128 x 128 output tiles
+    on the 256 CUs (a panel below one round runs at the small-grid rate and gains no overlap worth it); cfg4's 4096 x 4096
+    weight -> 4 panels of 1024 rows (256 tiles each), a 1024 x 1024 layer -> 1 (the literal single all-reduce)."""
+    tiles = -(-K // 128) * -(-N // 128)
+    return max(1, min(cap, tiles // 256, max(1, K // 256)))
+
+
 class GradSync:
     """Sums `.grad` of the given parameters across ranks after each backward().
 
-    One flat bucket holds every parameter gradient; the gradients the sweep ends with are views of it.
-    A parameter that is the right operand of a matmul (W in X @ W) gets its gradient X^T @ G computed in
-    `panels` ROW PANELS written straight into the bucket: panel i's all-reduce leaves (second stream) while
-    panel i+1's GEMM runs — on cfg4 the weight-gradient GEMM is the last kernel of the sweep, so without the
-    panels the whole collective would be exposed. The rest of the bucket (biases, parameters whose gradient
-    has several contributions) goes out in ONE collective when its last member is final."""
+    One flat bucket holds every parameter gradient, in the order the parameters were given; the gradients the sweep ends
+    with are views of it. A parameter that is the right operand of a matmul (W in X @ W) gets its gradient X^T @ G computed
+    in ROW PANELS written straight into the bucket: panel i's all-reduce leaves (second stream) while panel i+1's GEMM
+    runs — on cfg4 the weight-gradient GEMM is the last kernel of the sweep, so un-panelled the whole collective would be
+    exposed. Bucket neighbours whose gradient is already final (cfg4: the bias, bucket = [W || b]) ride on the adjacent
+    panel's collective, so the sweep issues `panels` collectives and no 16-KiB one of pure latency. Whatever is left goes
+    out in ONE collective per contiguous run when the last parameter is final, or — parameters the sweep never reported —
+    when the object is called at the end of the sweep (which raises if such a parameter has no gradient at all).
+    `panels`: None = by shape (`auto_panels`; MDHIP_DP_PANELS overrides), 1 = the single all-reduce of the whole bucket."""
 
     def __init__(self, md, params, comm, force=False, overlap=True, panels=None):
         import os
@@ -169,21 +180,21 @@ class GradSync:
         self.nbytes = int(sum(p.size * np.dtype(p.dtype).itemsize for p in self.params))
         self.active = not (comm is None or (comm.world == 1 and not force))
         self.overlap = bool(overlap and self.active and hasattr(md, "register_grad_ready_hook"))
-        if panels is None:
-            panels = int(os.environ.get("MDHIP_DP_PANELS", "4"))
+        if panels is None and os.environ.get("MDHIP_DP_PANELS"):
+            panels = int(os.environ["MDHIP_DP_PANELS"])
         # a communicator without an asynchronous form would serialise every panel behind a host sync
-        self.panels = max(1, int(panels)) if (self.overlap and hasattr(comm, "allreduce_sum_async_")) or isinstance(comm, HostComm) else 1
-        if not self.overlap:
-            self.panels = 1
-        self._ready = set()
-        self._paneled = set()   # ids of parameters whose gradient was produced (and sent) in panels this sweep
+        can_panel = self.overlap and (hasattr(comm, "allreduce_sum_async_") or isinstance(comm, HostComm))
+        self._panels_req = (max(1, int(panels)) if panels is not None else None) if can_panel else 1
+        self.panels = self._panels_req or 0   # what the last panelled gradient used (0: none produced yet, count by shape)
+        self._ready = set()     # ids of parameters reported final in this sweep
+        self._sent = set()      # ids of parameters whose bucket slot has been handed to a collective in this sweep
         self._in_flight = False
-        self.overlapped = 0  # sweeps whose collective(s) went out from inside backward()
+        self.overlapped = 0  # sweeps whose collective(s) all went out from inside backward()
         self.panel_collectives = 0
         self._slots = None
         if self.overlap:
             for p in self.params:
-                md.register_grad_ready_hook(p, self._on_ready, self._produce if self.panels > 1 else None)
+                md.register_grad_ready_hook(p, self._on_ready, self._produce if self._panels_req != 1 else None)
 
     # ---- bucket layout: one slot per parameter, in the order given -------------------------------------
     def _ensure_bucket(self):
@@ -202,6 +213,35 @@ class GradSync:
         pos, n = self._slots[id(p)]
         return self.bucket[pos:pos + n]
 
+    def _pack(self, p):
+        """Copy p's (final) gradient into its bucket slot and make the gradient a view of the slot."""
+        B = self.md.backend
+        g = p.grad
+        pos, n = self._slots[id(p)]
+        view = self.bucket[pos:pos + n]
+        view[...] = B.reshape(g._data if g.dtype == self.bucket.dtype else B.astype(g._data, self.bucket.dtype), (n,))
+        p.grad = self.md.Tensor(B.reshape(view, g.shape))
+
+    def _ride_along(self, w, lo, hi, first, last):
+        """Extend the bucket range [lo, hi) of w's first / last panel over neighbouring slots whose gradients are final
+        already and not yet sent (they are packed now): one collective instead of two."""
+        k = next(i for i, p in enumerate(self.params) if p is w)
+        if last:
+            for p in self.params[k + 1:]:
+                if id(p) not in self._ready or id(p) in self._sent or p.grad is None:
+                    break
+                self._pack(p)
+                self._sent.add(id(p))
+                hi = self._slots[id(p)][0] + self._slots[id(p)][1]
+        if first:
+            for p in reversed(self.params[:k]):
+                if id(p) not in self._ready or id(p) in self._sent or p.grad is None:
+                    break
+                self._pack(p)
+                self._sent.add(id(p))
+                lo = self._slots[id(p)][0]
+        return lo, hi
+
     # ---- gradient producer: weight gradient of a matmul, row panel by row panel --------------------------
     def _produce(self, node, index, grad):
         """Offered by the tape when `node.inputs[index]` (a hooked parameter) gets its single contribution.
@@ -212,34 +252,41 @@ class GradSync:
         x, w = node.inputs
         if getattr(x, "ndim", 0) != 2 or w.ndim != 2 or grad.ndim != 2 or w.dtype != self.params[0].dtype or grad.dtype != w.dtype:
             return None
-        if self._in_flight and not self._paneled:
-            raise RuntimeError("GradSync: the previous sweep's collective was never joined (call the GradSync object after backward())")
+        if id(w) in self._sent or id(w) in self._ready:
+            raise RuntimeError("GradSync: a second backward() reached a parameter whose gradient of THIS sweep has already been "
+                               "handed to the all-reduce (call the GradSync object after every backward())")
         B = self.md.backend
         self._ensure_bucket()
         K, N = w.shape
+        P = self._panels_req if self._panels_req is not None else auto_panels(K, N)
+        P = min(P, max(1, K // 256))
+        self.panels = P
+        pos_w = self._slots[id(w)][0]
         dest = B.reshape(self._slot_view(w), (K, N))
         xT = B.transpose(x._data if hasattr(x, "_data") else x)
         g = grad._data
-        P = min(self.panels, max(1, K // 256))
         step = -(-K // P)
         step = -(-step // 256) * 256 if K >= 512 else step   # whole GEMM tiles per panel
         allreduce = getattr(self.comm, "allreduce_sum_async_", self.comm.allreduce_sum_)
+        self._sent.add(id(w))
         r0 = 0
         while r0 < K:
             r1 = min(K, r0 + step)
             B.matmul(xT[r0:r1], g, out=dest[r0:r1])
-            allreduce(B.reshape(dest[r0:r1], ((r1 - r0) * N,)))
+            lo, hi = self._ride_along(w, pos_w + r0 * N, pos_w + r1 * N, first=r0 == 0, last=r1 == K)
+            allreduce(self.bucket[lo:hi])
             self.panel_collectives += 1
             r0 = r1
-        self._paneled.add(id(w))
         self._in_flight = True
         return self.md.Tensor(dest)
 
     def _on_ready(self, tensor):
+        if id(tensor) in self._ready:
+            raise RuntimeError("GradSync: a parameter's gradient was reported final twice before the sweep's collectives were "
+                               "joined (two backward() calls without calling the GradSync object in between)")
         self._ready.add(id(tensor))
         if len(self._ready) == len(self.params):
-            self._ready.clear()
-            self._reduce(asynchronous=True)
+            self._reduce_rest(asynchronous=True)
             self._in_flight = True
             self.overlapped += 1
 
@@ -252,47 +299,51 @@ class GradSync:
     def __call__(self):
         if not self.active:
             return
-        self._ready.clear()
-        if self._in_flight:  # issued from inside backward(): only join the streams
+        try:
+            if len(self._sent) < len(self.params):
+                # parameters the sweep never reported final (no hooks, or a parameter the graph did not use): reduce them now,
+                # on the compute stream (a synchronous all-reduce joins the in-flight ones first: one issue order per communicator)
+                self._reduce_rest(asynchronous=False)
+            if self._in_flight:
+                wait = getattr(self.comm, "wait", None)
+                if wait is not None:
+                    wait()
+        finally:
             self._in_flight = False
-            self._paneled.clear()
-            wait = getattr(self.comm, "wait", None)
-            if wait is not None:
-                wait()
-            return
-        self._reduce(asynchronous=False)
-        self._paneled.clear()
+            self._ready.clear()
+            self._sent.clear()
 
-    def _reduce(self, asynchronous):
-        """Everything that has not gone out in panels: packed in the bucket, one collective per contiguous run."""
+    def _reduce_rest(self, asynchronous):
+        """Everything that has not gone out yet: packed in the bucket, one collective per contiguous run of slots."""
         B = self.md.backend
         allreduce = self.comm.allreduce_sum_
         if asynchronous:
             allreduce = getattr(self.comm, "allreduce_sum_async_", allreduce)
-        grads = [p.grad for p in self.params]
-        if any(g is None for g in grads):
-            raise RuntimeError("GradSync: a parameter has no gradient (was backward() run?)")
-        if len(grads) == 1 and not self._paneled:
-            raw = grads[0]._data
+        rest = [p for p in self.params if id(p) not in self._sent]
+        if not rest:
+            return
+        if any(p.grad is None for p in rest):
+            raise RuntimeError("GradSync: a parameter has no gradient (was backward() run? is every parameter used by the sweep?)")
+        if len(self.params) == 1 and self.bucket is None:
+            raw = rest[0].grad._data
             if not _is_contiguous(raw):
                 raw = B.copy(raw)
                 self.params[0].grad = self.md.Tensor(raw)
+            self._sent.add(id(rest[0]))
             allreduce(raw)
             return
         self._ensure_bucket()
-        dt = self.bucket.dtype
         run = None  # [start, end) of the current run of not-yet-sent slots
         runs = []
-        for p, g in zip(self.params, grads):
+        for p in self.params:
             pos, n = self._slots[id(p)]
-            if id(p) in self._paneled:
+            if id(p) in self._sent:
                 if run is not None:
                     runs.append(run)
                     run = None
                 continue
-            view = self.bucket[pos:pos + n]
-            view[...] = B.reshape(g._data if g.dtype == dt else B.astype(g._data, dt), (n,))
-            p.grad = self.md.Tensor(B.reshape(view, g.shape))
+            self._pack(p)
+            self._sent.add(id(p))
             run = [pos, pos + n] if run is None else [run[0], pos + n]
         if run is not None:
             runs.append(run)

@@ -60,7 +60,7 @@ def main():
         del calls[:]
         bstep()
         bsync()
-        assert calls == [256 * 48] * 4 + [48], calls          # four W panels from inside the GEMM loop, then the bias slot
+        assert calls == [256 * 48] * 3 + [256 * 48 + 48], calls   # four W panels from inside the GEMM loop; the bias (final before W in backward order, next to W in the bucket) rides on the last one
         assert bsync.panel_collectives == 4 * (sweep + 1) and bsync.overlapped == sweep + 1
         for name in ("W", "b"):
             got, exp = bst[name].grad.as_numpy(), big_full[name].grad.as_numpy()
@@ -70,6 +70,21 @@ def main():
         # the gradients ARE views of the bucket (no copy of W.grad into it)
         assert np.shares_memory(bst["W"].grad._data, bsync.bucket) and np.shares_memory(bst["b"].grad._data, bsync.bucket)
     bsync.close()
+    # panel boundaries that do not divide the weight: K = 1280 in 3 requested panels -> whole 256-row GEMM tiles per panel
+    # (512, 512, 256 rows), the short last panel carrying the bias
+    ofull, ofull_step = workloads.make_cfg4(md, batch=64, d_in=1280, d_out=24, rank=0, world=1)
+    ofull_step()
+    ost, ostep = workloads.make_cfg4(md, batch=64, d_in=1280, d_out=24, rank=rank, world=world)
+    osync = dp.GradSync(md, ost["params"], comm, panels=3)
+    del calls[:]
+    ostep()
+    osync()
+    assert calls == [512 * 24, 512 * 24, 256 * 24 + 24], calls
+    for name in ("W", "b"):
+        got, exp = ost[name].grad.as_numpy(), ofull[name].grad.as_numpy()
+        assert np.abs(got - exp).max() / np.abs(exp).max() < 1e-5, name
+        assert np.shares_memory(ost[name].grad._data, osync.bucket)
+    osync.close()
     # un-chunked reference of the same sweep: bit-equal on this rank's shard sums? (different GEMM blocking may round
     # differently on a device; on NumPy the panel products are the same dot products) -> equal after the same all-reduce
     usync = dp.GradSync(md, bst["params"], comm, panels=1)

@@ -20,18 +20,21 @@ def _free_port():
     return p
 
 
-def test_dp_world2_gloo():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_dp_gloo(world):
+    """The sharded sweep + gradient all-reduce at 2, 4 and 8 ranks (the sizes the driver's scaling run uses): shard
+    coverage, panel boundaries (even and uneven), bucket views, gradients = full batch, rendezvous failure handling."""
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     try:
         for p in procs:
-            out, _ = p.communicate(timeout=300)
+            out, _ = p.communicate(timeout=600)
             outs.append(out)
     finally:
         for p in procs:
@@ -39,7 +42,7 @@ def test_dp_world2_gloo():
                 p.kill()
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
-        assert f"DP-OK rank {rank}/2" in out
+        assert f"DP-OK rank {rank}/{world}" in out
 
 
 def test_shard_rows():
@@ -96,6 +99,51 @@ def test_overlapped_allreduce_single_rank_gpu(engines, on_gpu):
 
 
 @pytest.mark.gpu
+def test_segmented_graph_replay_single_rank_gpu(engines, on_gpu):
+    """graph.SegmentedSweep: the data-parallel sweep replayed as hipGraph segments with the collectives between them
+    (world size 1, RCCL): same gradients as the eager sweep bit for bit, new inputs fed INTO the resident arrays are
+    picked up by a replay, and no Python tape runs during a replay."""
+    assert on_gpu
+    from minidiff_amd import dp, workloads
+    from minidiff_amd.graph import SegmentedSweep
+    hip, _ = engines
+    comm = dp.RcclComm(0, 1)
+    try:
+        st, step = workloads.make_cfg4(hip, batch=512, d_in=1024, d_out=256)
+        sync = dp.GradSync(hip, st["params"], comm, force=True, panels=2)
+
+        def sweep():
+            out = step()
+            sync()
+            return out
+
+        sweep()
+        ref = {k: st[k].grad.as_numpy().copy() for k in ("W", "b")}
+        seg = SegmentedSweep(sweep, comm)
+        # two panels (the second carries the bias) + the join: 3 communicator calls, a graph segment in front of each and one behind
+        assert seg.calls == 3 and seg.segments == 4, (seg.calls, seg.segments)
+        overlapped = sync.overlapped
+        for _ in range(3):
+            out = seg.replay()
+        assert sync.overlapped == overlapped            # replays run no Python
+        for k in ("W", "b"):
+            np.testing.assert_array_equal(out[k].grad.as_numpy(), ref[k])
+        # new batch written into the resident input: the replay computes ITS gradients
+        x2 = np.random.default_rng(11).standard_normal((512, 1024)).astype(np.float32)
+        st["X"]._data[...] = x2
+        out = seg.replay()
+        got = {k: out[k].grad.as_numpy().copy() for k in ("W", "b")}
+        seg.close()
+        sweep()
+        for k in ("W", "b"):
+            np.testing.assert_array_equal(got[k], st[k].grad.as_numpy())
+        assert not np.array_equal(got["W"], ref["W"])
+        sync.close()
+    finally:
+        comm.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("comm", ["rccl", "torch"])
 @pytest.mark.parametrize("workload", ["cfg2", "cfg4"])
 def test_bench_distributed_path_on_one_gpu(on_gpu, comm, workload):
@@ -114,5 +162,9 @@ def test_bench_distributed_path_on_one_gpu(on_gpu, comm, workload):
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["config"]["collective"] == ("rccl-direct" if comm == "rccl" else "rccl-torch"), line["config"]
     assert line["config"]["allreduce_bytes"] > 0 and line["value"] > 0
-    # every sweep's collective (pre-roll + warm-up + timed, + the detail pass of cfg4) left from inside backward()
-    assert line["config"]["allreduce_overlapped_sweeps"] == line["preroll_sweeps"] + 1 + 3 + 10 + (3 if workload == "cfg4" else 0)
+    # every sweep that ran through Python sent its collective(s) from inside backward(): pre-roll, 1 + 1 eager sweeps in front of
+    # the capture, the capturing run itself (the K timed sweeps are graph-segment replays: no Python), ten single synchronised
+    # sweeps and the detail pass of cfg4. The torch communicator has no asynchronous form, but is cut into segments all the same.
+    seg = line["config"]["graph_replay"]
+    assert isinstance(seg, dict) and seg["segments"] >= 2 and seg["collective_calls"] >= 2, seg
+    assert line["config"]["allreduce_overlapped_sweeps"] == line["preroll_sweeps"] + 1 + 1 + 1 + 10 + (3 if workload == "cfg4" else 0)
