@@ -456,6 +456,15 @@ template <int ROWS> __device__ __forceinline__ uint32_t glds_tile_lane_off(int64
   constexpr int LPR = ROWS / 4 > 64 ? 64 : ROWS / 4;   // lanes per k-row
   return (uint32_t)(((int64_t)(lane / LPR) * ks + (lane % LPR) * 4) * 4);
 }
+// A wave-uniform 64-bit address, made opaque to the optimiser as two scalar words: the DMA's address is then visibly
+// (scalar base) + (zero-extended 32-bit lane offset) and nothing else — left transparent, the compiler re-associated the sum of
+// several pieces as ((lane offset + k offset) + piece base), a 64-bit VECTOR add per piece, and the DMA took the per-lane 64-bit
+// address form (half the pieces of the NT kernel, scripts/isa_check.py). No instruction is emitted for this.
+__device__ __forceinline__ const char *md_opaque_uniform(const char *p) {
+  uint32_t lo = (uint32_t)(uintptr_t)p, hi = (uint32_t)((uintptr_t)p >> 32);
+  asm("" : "+s"(lo), "+s"(hi));
+  return reinterpret_cast<const char *>(((uintptr_t)hi << 32) | lo);
+}
 // `wbase` = the wave's first piece of tile 0 (uniform pointer: P + row0 + wave * KPP * ks), `step` = floats between a wave's consecutive
 // pieces (NW * KPP * ks), `koff` = floats from tile 0 to this k-tile (k0 * ks): adds only, in scalar registers.
 template <int ROWS, int BK, int NT, bool PRED = false>
@@ -463,7 +472,7 @@ __device__ __forceinline__ void glds_tile_pass_u(const float *wbase, int64_t ste
   constexpr int NW = NT / 64;
   static_assert(ROWS <= 256, "a piece covers whole k-rows");
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const char *ub = reinterpret_cast<const char *>(wbase + koff + (int64_t)i * step);
+  const char *ub = md_opaque_uniform(reinterpret_cast<const char *>(wbase + koff + (int64_t)i * step));
   // keeps the 32 -> 64-bit extension of the lane offset next to the DMA (address mode `v_offset, s[base]`; hoisted out of the loop it
   // arrives as a 64-bit register pair and the DMA takes the slow per-lane 64-bit form): an empty, NON-volatile statement that "depends" on
   // the k-tile offset, so it can neither leave the loop nor pin the instruction order
@@ -657,7 +666,10 @@ __device__ __forceinline__ void glds_kc_pass_u(const float *wbase, int64_t step,
   constexpr int NW = NT / 64, KH = BK / 16;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int rb = (i / KH) * NW + wave, kh = i % KH;
-  const char *ub = reinterpret_cast<const char *>(wbase + (int64_t)(i / KH) * step + k0 + kh * 16);
+  // (the k-half's 64 bytes ride in the LANE offset: with them in the base, two pieces 64 B apart were folded into one 64-bit per-lane
+  // address plus a constant and the DMAs fell back to the `v[N:N+1], off` form with a v_lshl_add_u64 each: scripts/isa_check.py)
+  const char *ub = md_opaque_uniform(reinterpret_cast<const char *>(wbase + (int64_t)(i / KH) * step + k0));
+  lane_off += (uint32_t)(kh * 64);
   asm("" : "+v"(lane_off) : "s"((int)k0));   // (as in glds_tile_pass_u)
   // `rows_left` = rows of the operand from this tile's first row on (rows-only ragged kernels; see glds_tile_pass_u)
   if (!PRED || (int)(threadIdx.x & 15) + rb * 16 < rows_left) __builtin_amdgcn_global_load_lds((md_gbl_void *)(ub + lane_off), (md_lds_void *)(S + (rb * KH + kh) * 256), 16, 0, 0);

@@ -166,5 +166,6 @@ def test_bench_distributed_path_on_one_gpu(on_gpu, comm, workload):
     # the capture, the capturing run itself (the K timed sweeps are graph-segment replays: no Python), ten single synchronised
     # sweeps and the detail pass of cfg4. The torch communicator has no asynchronous form, but is cut into segments all the same.
     seg = line["config"]["graph_replay"]
-    assert isinstance(seg, dict) and seg["segments"] >= 2 and seg["collective_calls"] >= 2, seg
+    # (cfg4 over RCCL: the weight-gradient panels + the join; the torch communicator has one synchronous all-reduce and no join)
+    assert isinstance(seg, dict) and seg["segments"] >= 2 and seg["collective_calls"] >= (2 if comm == "rccl" else 1), seg
     assert line["config"]["allreduce_overlapped_sweeps"] == line["preroll_sweeps"] + 1 + 1 + 1 + 10 + (3 if workload == "cfg4" else 0)
