@@ -224,6 +224,22 @@ def load() -> Library:
     """Return the process-wide library, loading the PRODUCT build on first use."""
     global _LIB
     if _LIB is None:
+        variant = os.environ.get("MDHIP_LIB_VARIANT")
+        if variant:
+            # EXPERIMENTS ONLY (scripts/gemm_ab.sh, prof_ab.sh, gemm_ablate.sh): an A/B build of the same gfx950 library
+            # under scripts/ab/ (`make -C minidiff_amd/csrc variant NAME=..`) — named explicitly, announced on stderr, never
+            # found by default. The product file itself is no longer swapped on the box by those scripts.
+            import sys
+            path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "ab", f"libmdhip_{variant}.so")
+            if not os.path.exists(path):
+                raise ImportError(f"MDHIP_LIB_VARIANT={variant}: {path} does not exist")
+            print(f"[mdhip] EXPERIMENT BUILD in use: {path}", file=sys.stderr)
+            lib = Library(path)
+            if lib.target != PRODUCT_TARGET:
+                raise ImportError(f"{path} reports target {lib.target!r}, expected {PRODUCT_TARGET!r}")
+            _LIB = lib
+            _LIB.ensure_init()
+            return _LIB
         if not os.path.exists(PRODUCT_LIB):
             raise ImportError(
                 f"{PRODUCT_LIB} is missing: the HIP extension has not been built. "

@@ -772,9 +772,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int c = j & 1;
-#ifndef MD_ABL_NOREAD
       if (j + 1 < NP) MD_KC_READ(CUR, j + 1, c ^ 1)
-#endif
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int sidx = j * 4 + t;
@@ -782,7 +780,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < PPS; ++q) {
           const int pi = sidx * PPS + q;
-#ifndef MD_ABL_NODMA
           if (pi < PA) {
             if constexpr (RAGGED == 1) glds_kc_pass<BM, BK, NT, true>(A, g.a_ms, m0, kn * BK, CUR ? A0 : A1, pi, g.M, g.K, g.zero);
             else if constexpr (RAGGED == 2) glds_kc_pass_u<BM, BK, NT, true>(wa, sa, kn * BK, CUR ? A0 : A1, pi, la, rla);
@@ -801,7 +798,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
             }
             ++n_dma;
           }
-#endif
         }
 #pragma unroll
         for (int i = 0; i < WTM; ++i)
@@ -822,12 +818,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
         }
       }
     }
-#ifndef MD_ABL_NOBAR
     __syncthreads();
-#endif
-#ifndef MD_ABL_NOREAD
     MD_KC_READ(CUR ^ 1, 0, 0)
-#endif
   };
   int64_t kt = 0;
   for (; kt + 1 < nk; kt += 2) {
@@ -1007,7 +999,8 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
         // whole k-tiles on the 128-row tiles: predicated lanes + scalar-base addresses (4100 x 4096 x 4100: 104-108 -> 112-124 TFLOP/s);
         // the 256x256 tile keeps the select form — the predicate's branch around each DMA splits its one scheduling region
         // (4000^3: 133-137 against 130 with the predicate)
-        if (ga.K % BK == 0 && BM <= 128) md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN, 2>, grid, 64 * WM * WN, ga);
+        // (the predicated form builds its addresses from 32-bit lane offsets: operand strides below 2^26 elements, as in the whole-tile branch)
+        if (ga.K % BK == 0 && BM <= 128 && ga.a_ks < (1ll << 26) && ga.b_ks < (1ll << 26)) md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN, 2>, grid, 64 * WM * WN, ga);
         else md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN, 1>, grid, 64 * WM * WN, ga);
       }
     }
@@ -1443,7 +1436,10 @@ extern "C" int mdhip_matmul_bias_relu_sum(const mdhip_array *a, const mdhip_arra
     return md_fail(MDHIP_EVALUE, "matmul_bias_relu_sum: shapes do not agree");
   const bool row_major = a->strides[1] == 1 && b->strides[1] == 1 && bias->strides[0] == 1 && mask_out->strides[1] == 1 && mask_out->strides[0] == N;
   auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
-  if (!row_major || !al16(a->data) || !al16(b->data) || (a->strides[0] & 3) || (b->strides[0] & 3) || K < 16 || (K % 16))
+  // (the epilogue writes the mask in 16-byte vectors and reads the bias per column: an offset bool view or a short bias view
+  // passed through the C-ABI must take the general path, not misaligned 16-byte stores)
+  if (!row_major || !al16(a->data) || !al16(b->data) || !al16(mask_out->data) || ((uintptr_t)bias->data & 3) || (N & 15) ||
+      (a->strides[0] & 3) || (b->strides[0] & 3) || K < 16 || (K % 16))
     return md_fail(MDHIP_EVALUE, "matmul_bias_relu_sum: layout not covered by the fused kernel");
   GemmArgs ga{};
   ga.A = (const float *)a->data; ga.B = (const float *)b->data; ga.C = nullptr;

@@ -177,14 +177,17 @@ class SweepCache:
     (step, hash); it is only replayed while the sweep keeps that structure:
       * a run whose hash differs from the previous one of the same `step` (another branch taken, another op) is
         simply a different entry: it runs eagerly, then captures its own graph;
-      * a replay executes no Python, so it cannot see a change by itself: every `validate_every`-th call of a
-        captured entry runs eagerly instead and compares hashes; on a mismatch the stale graph is destroyed.
+      * a replay executes no Python, so it cannot see a change by itself: every `validate_every`-th call (default 64; 0 =
+        never) of a captured entry runs eagerly instead and compares keys; on a mismatch the stale graph is destroyed.
+    The key is the structural hash PLUS the tape's sweep signature (`tape._signature`: which inputs are the same tensor,
+    shared intermediates, leaf shapes / dtypes, scalar constants, keyword arguments) — the structural hash alone maps every
+    leaf and scalar to -1, so sum(sin(a)*sin(a)) and sum(sin(a)*sin(b)) would collide.
     A sweep that cannot be captured (a synchronising call inside it; the CPU test double) stays eager.
     `step` should RETURN the arrays it produces (e.g. the gradient tensors): a replay rewrites those very arrays,
     but it runs no Python, so attributes that the sweep rebinds (`x.grad = ...`) keep pointing at whatever the
     last Python-executed run left there."""
 
-    def __init__(self, md, validate_every: int = 0):
+    def __init__(self, md, validate_every: int = 64):
         self.md = md
         self.validate_every = int(validate_every)
         self._entries = {}      # (id(step), hash) -> dict(seen, sweep, failed)
@@ -196,10 +199,15 @@ class SweepCache:
     def _lib_sync():
         (_capi.current() or _capi.load()).sync()
 
+    def _key(self):
+        # the structural hash alone maps every leaf and scalar to -1 (as the reference's does): two sweeps that differ only in
+        # WHICH inputs coincide, in shapes or in constants would share it, and a stale graph would replay silently
+        return (self.md.last_root_hash, getattr(self.md, "last_root_signature", None))
+
     def _eager(self, step):
-        with self.md.reuse_graph():
+        with self.md.reuse_graph():   # (a fresh traversal table per Python-run sweep: the tape's memo is keyed by the structural hash alone)
             out = step()
-            return out, self.md.last_root_hash
+            return out, self._key()
 
     def run(self, step):
         sid = id(step)
@@ -222,9 +230,9 @@ class SweepCache:
         if entry is not None and entry["seen"] >= 1 and not entry["failed"]:
             # second sighting of this structure: capture it (the capture run executes the sweep once more)
             try:
-                with self.md.reuse_graph():
+                with self.md.reuse_graph():   # (a fresh traversal table per Python-run sweep: the tape's memo is keyed by the structural hash alone)
                     sweep = CapturedSweep(step, warmup=0)
-                    h2 = self.md.last_root_hash
+                    h2 = self._key()
             except RuntimeError:
                 entry["failed"] = True
                 self.stats["uncapturable"] += 1

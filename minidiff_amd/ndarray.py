@@ -243,6 +243,7 @@ class DeviceArray:
         prog, keep = _lz.build_program(e, self.shape)
         self._buf = _Buffer(_prod(self.shape) * self.dtype.itemsize)
         self._expr = None
+        saved_tasks, claimed = self._tasks, []
         try:
             tasks = self._live_tasks()
             if self.size:
@@ -252,6 +253,7 @@ class DeviceArray:
                     t = tasks[0]
                     res = t.res
                     t.claim()
+                    claimed.append(t)
                     try:
                         _lib().vm_eval_reduce_cols(prog, t.code, self.desc(), res.desc())
                         FUSION_STATS["vm_eval_reduce_cols"] += 1
@@ -264,11 +266,17 @@ class DeviceArray:
                 for k, t in enumerate(tasks):
                     if t is not fused:  # from the materialised value (one more read, same result)
                         r = res if k == 0 else t.res
-                        t.claim()
+                        if t not in claimed:
+                            t.claim()
+                            claimed.append(t)
                         _lib().reduce(t.code, self.desc(), r.desc(), 1)
         except BaseException:
-            # the launch did not happen: the array must not look materialised over an unwritten block
+            # the launch did not happen: the array must not look materialised over an unwritten block, and the column sums
+            # that were claimed for this pass are owed again (their result blocks are still unfilled)
             self._buf, self._expr, self._cdesc = None, e, None
+            for t in claimed:
+                t.unclaim(self)
+            self._tasks = saved_tasks
             raise
         del keep
 
@@ -1514,6 +1522,14 @@ class _ColsTask:
             b.task = None
         self.src = None
 
+    def unclaim(self, src):
+        """The pass that claimed the task failed before filling `res`: owed again."""
+        self.done = False
+        self.src = src
+        b = self._buf()
+        if b is not None:
+            b.task = self
+
     def run(self):
         if self.done:
             return
@@ -2458,6 +2474,11 @@ def random_integers(low, high, shape, dtype=np.int64):
         raise ValueError("low >= high")
     if high - low > (1 << 53):
         raise ValueError("device RNG: integer ranges up to 2**53")
+    info = np.iinfo(np.dtype(dtype))   # NumPy's own bounds check (np.random.randint): no silent wrap into a narrower dtype
+    if low < info.min:
+        raise ValueError(f"low is out of bounds for {np.dtype(dtype).name}")
+    if high - 1 > info.max:
+        raise ValueError(f"high is out of bounds for {np.dtype(dtype).name}")
     return _random_fill(_RNG_INTEGERS, shape, np.dtype(dtype), low, high - low, words_per_elem=2)
 
 

@@ -51,6 +51,35 @@ def _visit_paths(node, prefix, seen, out):
         out.append(path)
 
 
+def _signature(root):
+    """What a REPLAY of a recorded sweep depends on and the structural hash leaves out (it maps every leaf and every
+    non-tensor to -1, as the reference's topology.py:52-63 does): which inputs are the SAME tensor (sin(a)*sin(a) vs
+    sin(a)*sin(b)), which intermediates are shared, leaf shapes and dtypes, scalar constants and keyword arguments. One int
+    per graph; every node is hashed once (graph.SweepCache keys captured hipGraphs by (structural hash, this))."""
+    leaf_index, memo = {}, {}
+
+    def node_sig(node):
+        got = memo.get(id(node))
+        if got is not None:
+            return ("R", got[1])                      # a shared intermediate: by its first-visit index
+        index = len(memo)
+        memo[id(node)] = (None, index)
+        parts = [node.name, tuple(sorted((k, repr(v)) for k, v in node.kwargs.items()))]
+        for x in node.inputs:
+            if hasattr(x, "op_node"):
+                if x.op_node is None or getattr(x, "is_leaf", False):
+                    parts.append(("L", leaf_index.setdefault(id(x), len(leaf_index)), tuple(x.shape), str(x.dtype)))
+                else:
+                    parts.append(node_sig(x.op_node))
+            else:
+                parts.append(("C", type(x).__name__, repr(x)))
+        h = hash(tuple(parts))
+        memo[id(node)] = (h, index)
+        return ("N", h)
+
+    return hash(node_sig(root))
+
+
 def build_engine(B, name: str = "engine"):
     """Create the md-like namespace (Tensor, ops, helpers) over backend table `B`."""
     E = types.SimpleNamespace()
@@ -101,11 +130,16 @@ def build_engine(B, name: str = "engine"):
     cached_paths = ContextVar(f"{name}_cached_indices", default=None)
     E.last_root_hash = None
 
+    E.last_root_signature = None
+
     class reuse_graph:
+        def __init__(self, table=None):
+            self.table = table   # a dict to keep the memoised traversals in ACROSS scopes (graph.SweepCache); None: a fresh one
+
         def __enter__(self):
             self.prev = (caching_on.get(), cached_paths.get())
             caching_on.set(True)
-            cached_paths.set({})
+            cached_paths.set({} if self.table is None else self.table)
             return self
 
         def __exit__(self, *exc):
@@ -153,7 +187,7 @@ def build_engine(B, name: str = "engine"):
     class Node:
         """One recorded op: inputs + one vjp closure per input."""
 
-        __slots__ = ("vjps", "inputs", "kwargs", "name", "pass_kwargs", "tensor_inputs", "op_ids")
+        __slots__ = ("vjps", "inputs", "kwargs", "name", "pass_kwargs", "tensor_inputs", "op_ids", "_hash")
 
         def __init__(self, vjps, inputs, kwargs, name, pass_kwargs):
             self.vjps = vjps
@@ -166,18 +200,21 @@ def build_engine(B, name: str = "engine"):
                 t.graph_refs += 1
             self.op_ids = None
             if caching_on.get():  # structural id (topology.py:52-63)
+                # (a producer enters by its HASH, not by its nested id tuple: tuple hashes are not cached, and hashing nested
+                # tuples re-walks a shared node once per path to it — exponential on graphs that reuse intermediates)
                 ids = []
                 for x in inputs:
                     if not isinstance(x, Tensor) or x.is_leaf or x.op_node is None or x.op_node.op_ids is None:
                         ids.append(-1)
                     else:
-                        ids.append(x.op_node.op_ids)
+                        ids.append(x.op_node.hash)
                 ids.append(self.name)
                 self.op_ids = tuple(ids)
+                self._hash = hash(self.op_ids)
 
         @property
         def hash(self):
-            return hash(self.op_ids)
+            return self._hash if self.op_ids is not None else hash(None)
 
         def push(self, grad, pending=None):
             """Chain rule for this node: evaluate each vjp, undo broadcasting, accumulate.
@@ -228,6 +265,7 @@ def build_engine(B, name: str = "engine"):
                         node = t.op_node
                     path.append(t)
                 E.last_root_hash = self.hash
+                E.last_root_signature = _signature(self)
             else:
                 path = _toposort(self)
             if reset_grads:

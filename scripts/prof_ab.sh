@@ -1,12 +1,11 @@
 #!/bin/bash
 # usage: prof_ab.sh TAG WORKLOAD "BENCH FLAGS" LIB...   (LIB = "main" or a name under scripts/ab/)
-# rocprofv3 kernel stats of bench.py with each library build in turn (the box's copy of libmdhip.so is swapped)
+# rocprofv3 kernel stats of bench.py with each library build in turn (selected by MDHIP_LIB_VARIANT: the product file is never touched)
 tag=$1; wl=$2; flags=$3; shift 3
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
-cp minidiff_amd/libmdhip.so /tmp/libmdhip_main.so
 for lib in "$@"; do
-  if [ $lib = main ]; then cp /tmp/libmdhip_main.so minidiff_amd/libmdhip.so; else cp scripts/ab/libmdhip_$lib.so minidiff_amd/libmdhip.so; fi
+  if [ $lib = main ]; then unset MDHIP_LIB_VARIANT; else export MDHIP_LIB_VARIANT=$lib; fi
   for rep in 1 2; do
     d=$out/${wl}_${lib}_$rep
     rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline $flags > $d.log 2>&1 || exit 1
@@ -21,4 +20,3 @@ for r in csv.DictReader(open(sys.argv[1])):
 PY
   done
 done
-cp /tmp/libmdhip_main.so minidiff_amd/libmdhip.so

@@ -151,6 +151,9 @@ def _backend_table(on_gpu, want_gpu):
         assert (r.shape, r.dtype) == ((6, 5), np.float64) and (z.shape, z.dtype) == ((2, 3, 4), np.float64)
         assert (k.shape, k.dtype) == ((7,), np.int64) and 0 <= int(k.get().min()) and int(k.get().max()) < 10
         assert k2.dtype == np.int32 and set(np.unique(k2.get())) <= {-2, -1, 0, 1, 2}
+        for lo, hi in ((0, 2 ** 31 + 1), (-2 ** 31 - 1, 0)):      # NumPy's bounds check for the requested dtype: no silent wrap-around
+            with pytest.raises(ValueError, match="out of bounds"):
+                T.randint(lo, hi, (3,), np.int32)
         assert b.dtype == np.int64 and set(np.unique(b.get())) <= {0, 1}
         assert np.array_equal(np.sort(perm.get()), np.arange(50))
         x = nd.asarray(np.arange(60, dtype=np.float32).reshape(20, 3))

@@ -125,6 +125,44 @@ def test_reuse_graph_memoises_traversal_by_structure(engines):
             md.backward_paths_for_root(a[2].op_node)     # "Not currently preserving graph" (caching.py:33-34)
 
 
+def test_sweep_signature_separates_what_the_structural_hash_merges(engines):
+    """the structural hash maps every leaf and scalar to -1 (as the reference's does), so
+    sum(sin(a)*sin(a)) and sum(sin(a)*sin(b)) share it — a hipGraph captured for one would replay for the other and
+    leave b.grad untouched. graph.SweepCache keys on (hash, tape signature): the signature tells them apart, and also
+    shapes, scalar constants, keyword arguments and shared intermediates."""
+    from minidiff_amd.graph import SweepCache
+    for md in engines:
+        a = md.Tensor(np.arange(6.0).reshape(2, 3) / 4, allow_grad=True)
+        b = md.Tensor(np.arange(6.0).reshape(2, 3) / 8, allow_grad=True)
+        c = md.Tensor(np.arange(4.0) / 8, allow_grad=True)
+        keys = {}
+        cache = SweepCache(md)
+
+        def key_of(name, fn):
+            with md.reuse_graph():
+                fn().backward()
+                keys[name] = cache._key()
+
+        key_of("aa", lambda: md.sum(md.sin(a) * md.sin(a)))
+        key_of("ab", lambda: md.sum(md.sin(a) * md.sin(b)))
+        key_of("aa2", lambda: md.sum(md.sin(a) * md.sin(a)))
+        def shared():
+            s = md.sin(a)
+            return md.sum(s * s)                        # ONE sin node used twice: another kernel sequence than sin(a)*sin(a)
+        key_of("shared", shared)
+        key_of("pow2", lambda: md.sum(a ** 2))
+        key_of("pow3", lambda: md.sum(a ** 3))
+        key_of("shape", lambda: md.sum(md.sin(c) * md.sin(c)))
+        key_of("axis0", lambda: md.sum(md.sum(a * b, axis=(0,))))
+        key_of("axis1", lambda: md.sum(md.sum(a * b, axis=(1,))))
+        assert keys["aa"][0] == keys["ab"][0]           # the reference-style hash cannot tell them apart ...
+        assert keys["aa"] != keys["ab"]                 # ... the cache key can
+        assert keys["aa"] == keys["aa2"]
+        assert len({keys[k] for k in ("aa", "ab", "shared", "shape")}) == 4
+        assert keys["pow2"] != keys["pow3"] and keys["axis0"] != keys["axis1"]
+        cache.close()
+
+
 def test_sweep_cache_falls_back_to_eager_on_cpu_double(engines, on_gpu):
     if on_gpu:
         pytest.skip("CPU double behaviour")

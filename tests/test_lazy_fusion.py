@@ -287,6 +287,35 @@ def test_deferred_cols_cpu(lazy_nd, on_gpu): _deferred_cols(lazy_nd, on_gpu, Fal
 def test_deferred_cols_gpu(lazy_nd, on_gpu): _deferred_cols(lazy_nd, on_gpu, True)
 
 
+def test_failed_one_pass_launch_leaves_the_column_sum_owed(lazy_nd, monkeypatch):
+    """the fused eval + column-sum pass claims the owed column sum BEFORE the launch. If the launch then fails
+    with anything but the "shape not covered" ValueError (an allocation failure, say), the claimed task must be owed
+    again — otherwise its result block stays unwritten and is later read as valid data."""
+    nd = lazy_nd
+    rng = np.random.default_rng(6)
+    z = rng.standard_normal((640, 1024)).astype(np.float32)
+    dz = nd.asarray(z)
+    g = nd.multiply(nd.greater(dz, 0), 1.5)
+    cs = nd.sum(g, axis=0)
+    assert g._buf is None and cs._buf.task is not None
+    real = nd._lib().vm_eval_reduce_cols
+
+    def boom(*a, **k):
+        raise MemoryError("injected: partial rows could not be allocated")
+
+    monkeypatch.setattr(nd._lib(), "vm_eval_reduce_cols", boom)
+    try:
+        with pytest.raises(MemoryError):
+            g.materialize()
+    finally:
+        monkeypatch.undo()
+    assert g._buf is None and cs._buf.task is not None and not cs._buf.task.done   # owed again, nothing looks materialised
+    exp = (np.float32(1.5) * (z > 0)).astype(np.float32)
+    _close(cs.get(), exp.sum(axis=0, dtype=np.float64), 1e-6)                      # and still computed correctly when needed
+    assert np.array_equal(g.get(), exp)
+    assert real is not None
+
+
 def _sincos_hoist(nd, on_gpu, want_gpu):
     """sin(x) and cos(x) of one leaf inside a fused program come from ONE sincos (fusion_jit.inc):
     the values must equal the eager kernels' bit for bit, for small and for huge arguments."""
