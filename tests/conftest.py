@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HOST_DOUBLE = os.path.join(ROOT, "oracle", "_build", "libmdhip_host.so")
+# (MDHIP_HOST_DOUBLE: another build of the double — the ASan + UBSan one of tests/test_sanitized_double.py)
+HOST_DOUBLE = os.environ.get("MDHIP_HOST_DOUBLE") or os.path.join(ROOT, "oracle", "_build", "libmdhip_host.so")
 
 
 def pytest_configure(config):
