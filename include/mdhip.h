@@ -55,7 +55,19 @@ enum {
   MDHIP_I64 = 2,
   MDHIP_F32 = 3,
   MDHIP_F64 = 4,
-  MDHIP_NUM_DTYPES = 5
+  MDHIP_NUM_DTYPES = 5, /* the COMPUTE dtypes: every arithmetic entry point takes these and only these */
+  /* Storage-only dtypes — the other names of the reference table (numpy.py:188-200: float16, uint8/16/32/64, int8/16).
+   * Arrays of these types live in device memory and are moved by mdhip_h2d / mdhip_d2h and converted by mdhip_convert;
+   * arithmetic on them is promote -> compute in a wide type -> demote, decided on the host (what NumPy's own float16
+   * loops do; integer wrap-around falls out of the truncating conversion). */
+  MDHIP_I8 = 5,
+  MDHIP_I16 = 6,
+  MDHIP_U8 = 7,
+  MDHIP_U16 = 8,
+  MDHIP_U32 = 9,
+  MDHIP_U64 = 10,
+  MDHIP_F16 = 11, /* IEEE binary16 */
+  MDHIP_NUM_ALL_DTYPES = 12
 };
 
 typedef struct mdhip_array {
@@ -187,6 +199,11 @@ int mdhip_graph_destroy(void *graph);
 /* out = op(x). `out` describes freshly allocated (or in-place) memory with the
  * result dtype chosen by the caller from NumPy's type resolution. */
 int mdhip_unary(int op, const mdhip_array *x, const mdhip_array *out);
+/* out = x converted element by element (C conversion rules = numpy.ndarray.astype's unsafe casting; to bool: x != 0;
+ * binary16 <-> wider floats with round-to-nearest-even), ANY pair of the 12 dtypes above, any strides (<= 8-D): the one
+ * kernel behind the storage-only dtypes — `astype`, strided copies, and the promote / demote steps around wide arithmetic.
+ * Replaces numpy.py:188-200's dtypes as used through `astype` (reference: minidiff/tensor.py:105, backend/numpy.py:19). */
+int mdhip_convert(const mdhip_array *x, const mdhip_array *out);
 /* out = op(a, b) with NumPy broadcasting already applied by the caller:
  * a, b and out have the same ndim/shape; broadcast axes carry stride 0.
  * compute_dtype = the ufunc loop dtype NumPy resolves (np.<op>.resolve_dtypes). */

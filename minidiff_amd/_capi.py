@@ -22,6 +22,7 @@ UID_BYTES = 128
 
 # dtype codes (mdhip.h)
 BOOL, I32, I64, F32, F64 = range(5)
+I8, I16, U8, U16, U32, U64, F16 = range(5, 12)   # storage-only dtypes (include/mdhip.h): moved and converted, never computed in
 
 # op codes — keep in the order of the enums in mdhip.h
 U_COPY, U_ABS, U_NEG, U_SIGN, U_CEIL, U_FLOOR, U_SIN, U_COS, U_TAN, U_SINH, U_COSH, U_TANH, \
@@ -113,6 +114,7 @@ _PROTOTYPES = {
     "mdhip_graph_launch": [C.c_void_p],
     "mdhip_graph_destroy": [C.c_void_p],
     "mdhip_unary": [C.c_int, _P(ArrayDesc), _P(ArrayDesc)],
+    "mdhip_convert": [_P(ArrayDesc), _P(ArrayDesc)],
     "mdhip_binary": [C.c_int, _P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc), C.c_int],
     "mdhip_where": [_P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc)],
     "mdhip_fill": [_P(ArrayDesc), _P(ArrayDesc)],

@@ -561,11 +561,41 @@ template <class T> __global__ void __launch_bounds__(MD_BLOCK) k_arange(T *out, 
   }
 }
 
+// ------------------------------------------------------------- any -> any conversion ----
+// The kernel behind the storage-only dtypes (include/mdhip.h: int8/16, uint8/16/32/64, float16): loads through the source's
+// carrier (int64 / uint64 / double), stores with the destination's conversion; the dtype switches are wave-uniform. Off the
+// BASELINE paths (nothing there uses a narrow type): one generic strided walk.
+template <class C>
+__global__ void __launch_bounds__(MD_BLOCK) k_convert(MdIter it, const void *x, int xdt, void *out, int odt) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < it.total; i += stride) {
+    int64_t offs[MD_MAX_OPS];
+    md_iter_offsets(it, i, offs);
+    md_store_any<C>(out, odt, offs[1], md_load_any<C>(x, xdt, offs[0]));
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
 int mdhip_unary(int op, const mdhip_array *x, const mdhip_array *out) { return md_unary_dispatch<HipExec>(op, x, out); }
+
+int mdhip_convert(const mdhip_array *x, const mdhip_array *out) {
+  MD_TRY(md_check_any_array(x, "convert x"));
+  MD_TRY(md_check_any_array(out, "convert out"));
+  MdIter it;
+  const mdhip_array *ops[2] = {x, out};
+  MD_TRY(md_build_iter(&it, 2, ops, out));
+  if (it.total == 0) return MDHIP_OK;
+  const int grid = md_grid_for(it.total);
+  switch (md_dtype_carrier(x->dtype)) {
+    case 2: k_convert<double><<<grid, MD_BLOCK, 0, md_stream()>>>(it, x->data, x->dtype, out->data, out->dtype); break;
+    case 1: k_convert<uint64_t><<<grid, MD_BLOCK, 0, md_stream()>>>(it, x->data, x->dtype, out->data, out->dtype); break;
+    default: k_convert<int64_t><<<grid, MD_BLOCK, 0, md_stream()>>>(it, x->data, x->dtype, out->data, out->dtype); break;
+  }
+  return MD_LAUNCH_CHECK("convert");
+}
 
 int mdhip_binary(int op, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out, int cdt) {
   return md_binary_dispatch<HipExec>(op, a, b, out, cdt);

@@ -35,6 +35,10 @@ static inline size_t md_dtype_size(int dt) {
     case MDHIP_I64: return 8;
     case MDHIP_F32: return 4;
     case MDHIP_F64: return 8;
+    case MDHIP_I8: case MDHIP_U8: return 1;
+    case MDHIP_I16: case MDHIP_U16: case MDHIP_F16: return 2;
+    case MDHIP_U32: return 4;
+    case MDHIP_U64: return 8;
   }
   return 0;
 }
@@ -45,6 +49,13 @@ static inline const char *md_dtype_name(int dt) {
     case MDHIP_I64: return "int64";
     case MDHIP_F32: return "float32";
     case MDHIP_F64: return "float64";
+    case MDHIP_I8: return "int8";
+    case MDHIP_I16: return "int16";
+    case MDHIP_U8: return "uint8";
+    case MDHIP_U16: return "uint16";
+    case MDHIP_U32: return "uint32";
+    case MDHIP_U64: return "uint64";
+    case MDHIP_F16: return "float16";
   }
   return "?";
 }
@@ -89,6 +100,97 @@ template <class Tc> static inline Tc md_scalar_as(const mdhip_array *s) {
   } else {
     return md_dtype_is_float(s->dtype) ? md_cast<Tc>(s->scalar_f) : md_cast<Tc>(s->scalar_i);
   }
+}
+
+// ---- storage-only dtypes: conversion through a carrier (mdhip_convert) ---------------
+// binary16 by bit manipulation (no _Float16 in the host toolchain): exact widening, round-to-nearest-even narrowing
+// straight from double (a float widens to double exactly, so one routine serves both without double rounding)
+MD_HD double md_half_to_double(uint16_t h) {
+  const uint32_t sign = (h >> 15) & 1u, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+  double v;
+  if (e == 0) v = (double)m * 5.9604644775390625e-08;                 // subnormal: m * 2^-24
+  else if (e == 31) { v = m ? __builtin_nan("") : __builtin_inf(); }
+  else {
+    uint64_t bits = ((uint64_t)(e + 1008u) << 52) | ((uint64_t)m << 42);   // exponent bias 1023 - 15
+    __builtin_memcpy(&v, &bits, 8);
+  }
+  return sign ? -v : v;
+}
+MD_HD uint16_t md_double_to_half(double d) {
+  uint64_t b;
+  __builtin_memcpy(&b, &d, 8);
+  const uint16_t sign = (uint16_t)((b >> 48) & 0x8000u);
+  const int64_t e = (int64_t)((b >> 52) & 0x7FF) - 1023;
+  uint64_t m = b & 0xFFFFFFFFFFFFFull;
+  if (e == 1024) return (uint16_t)(sign | 0x7C00u | (m ? 0x200u : 0u));           // inf / nan
+  if (e > 15) return (uint16_t)(sign | 0x7C00u);                                    // overflow -> inf
+  if (e >= -14) {                                                                   // normal half
+    uint64_t q = m >> 42, rem = m & ((1ull << 42) - 1), half = 1ull << 41;
+    uint32_t r = (uint32_t)(((uint64_t)(e + 15) << 10) | q);
+    if (rem > half || (rem == half && (r & 1u))) ++r;                               // carries into the exponent correctly, up to inf
+    return (uint16_t)(sign | r);
+  }
+  if (e < -25) return sign;                                                         // below half of the smallest subnormal
+  m |= 1ull << 52;                                                                  // subnormal half: value = m * 2^(e-52), unit 2^-24
+  const int shift = (int)(28 - e);                                                  // 52 - (e + 24)
+  uint64_t q = m >> shift, rem = m & ((1ull << shift) - 1), half = 1ull << (shift - 1);
+  if (rem > half || (rem == half && (q & 1u))) ++q;
+  return (uint16_t)(sign | (uint16_t)q);
+}
+// carrier of a dtype: 0 = int64 (signed ints, bool), 1 = uint64 (unsigned ints), 2 = double (floats)
+static inline int md_dtype_carrier(int dt) {
+  switch (dt) {
+    case MDHIP_F32: case MDHIP_F64: case MDHIP_F16: return 2;
+    case MDHIP_U8: case MDHIP_U16: case MDHIP_U32: case MDHIP_U64: return 1;
+  }
+  return 0;
+}
+template <class C> MD_HD C md_load_any(const void *p, int dt, int64_t off) {
+  switch (dt) {
+    case MDHIP_BOOL: return (C)(((const uint8_t *)p)[off] != 0);
+    case MDHIP_I8: return (C)((const int8_t *)p)[off];
+    case MDHIP_I16: return (C)((const int16_t *)p)[off];
+    case MDHIP_I32: return (C)((const int32_t *)p)[off];
+    case MDHIP_I64: return (C)((const int64_t *)p)[off];
+    case MDHIP_U8: return (C)((const uint8_t *)p)[off];
+    case MDHIP_U16: return (C)((const uint16_t *)p)[off];
+    case MDHIP_U32: return (C)((const uint32_t *)p)[off];
+    case MDHIP_U64: return (C)((const uint64_t *)p)[off];
+    case MDHIP_F16: return (C)md_half_to_double(((const uint16_t *)p)[off]);
+    case MDHIP_F32: return (C)((const float *)p)[off];
+  }
+  return (C)((const double *)p)[off];
+}
+template <class C> MD_HD int64_t md_carrier_to_i64(C v) {
+  if constexpr (sizeof(C) == 8 && !(C(0.5) > C(0))) return (int64_t)v;      // integer carriers: same bits
+  else return (v >= (C)9223372036854775808.0) ? (int64_t)(uint64_t)v : (int64_t)v;   // double: values of the upper unsigned half keep their bits
+}
+template <class C> MD_HD void md_store_any(void *p, int dt, int64_t off, C v) {
+  constexpr bool is_float = C(0.5) > C(0);
+  switch (dt) {
+    case MDHIP_BOOL: ((uint8_t *)p)[off] = (uint8_t)(v != (C)0); return;
+    case MDHIP_F16: ((uint16_t *)p)[off] = md_double_to_half((double)v); return;
+    case MDHIP_F32: ((float *)p)[off] = (float)v; return;
+    case MDHIP_F64: ((double *)p)[off] = (double)v; return;
+  }
+  // integer destinations: through 64 bits, then truncation (two's complement wrap-around, as C / NumPy's unsafe cast)
+  int64_t i;
+  if constexpr (is_float) i = md_carrier_to_i64(v);
+  else i = (int64_t)v;
+  switch (dt) {
+    case MDHIP_I8: case MDHIP_U8: ((uint8_t *)p)[off] = (uint8_t)i; return;
+    case MDHIP_I16: case MDHIP_U16: ((uint16_t *)p)[off] = (uint16_t)i; return;
+    case MDHIP_I32: case MDHIP_U32: ((uint32_t *)p)[off] = (uint32_t)i; return;
+    default: ((uint64_t *)p)[off] = (uint64_t)i; return;
+  }
+}
+// checks + iteration space of mdhip_convert, shared by the library and the test double
+static inline int md_check_any_array(const mdhip_array *a, const char *what) {
+  if (!a) return md_fail(MDHIP_EVALUE, "%s: null descriptor", what);
+  if (a->dtype < 0 || a->dtype >= MDHIP_NUM_ALL_DTYPES) return md_fail(MDHIP_ETYPE, "%s: unknown dtype code %d", what, a->dtype);
+  if (a->is_scalar) return md_fail(MDHIP_EVALUE, "%s: scalar descriptors are not accepted", what);
+  if (a->ndim < 0 || a->ndim > MDHIP_MAX_NDIM) return md_fail(MDHIP_EVALUE, "%s: ndim %d out of range (max %d)", what, a->ndim, MDHIP_MAX_NDIM);
+  return MDHIP_OK;
 }
 
 // ---- collapsed N-operand iteration space --------------------------------------

@@ -1,0 +1,195 @@
+"""Storage-only dtypes: float16, int8/16, uint8/16/32/64 — the names of the reference table
+(minidiff/backend/numpy.py:188-200) beyond the five the kernels compute in.
+
+Arrays of these types live in device memory like any other (views, transfers, `astype`, strided copies: one conversion
+kernel, `mdhip_convert`). Arithmetic on them is
+
+    promote to a wide device type  ->  the ordinary kernel  ->  demote to NumPy's result dtype
+
+which is what NumPy's own float16 loops do (compute in float32, round once), and exact for the integers: the low bits
+of a sum / difference / product / power computed in 64 bits are the narrow result, so NumPy's wrap-around falls out of
+the truncating conversion; comparisons, divisions and reductions see the true values. NumPy's result dtype (and the
+exception it raises for a combination it rejects) comes from running the SAME NumPy function on one-element host
+dummies of the operands' dtypes — no promotion table restated here.
+
+uint64 rides in int64 with the same bits: every function that looks at VALUES (not just bits) first checks that no
+element is >= 2**63 and raises TypeError otherwise — loud, not wrong.
+
+Nothing on a BASELINE path uses these types; the cost on the wide paths is one flag test per call (`install`)."""
+from __future__ import annotations
+
+import numpy as np
+
+_WIDE = {
+    np.dtype(np.int8): np.dtype(np.int64), np.dtype(np.int16): np.dtype(np.int64),
+    np.dtype(np.uint8): np.dtype(np.int64), np.dtype(np.uint16): np.dtype(np.int64), np.dtype(np.uint32): np.dtype(np.int64),
+    np.dtype(np.uint64): np.dtype(np.int64),   # same bits (range-checked where values matter)
+    np.dtype(np.float16): np.dtype(np.float32),
+}
+_U64 = np.dtype(np.uint64)
+NARROW_CODE_MIN = 5   # _capi.I8: DeviceArray._code >= this <=> storage-only dtype
+
+# functions that move elements without looking at their values: uint64 needs no range check there
+_MOVERS = {"concatenate", "stack", "tile", "repeat", "split", "getitem", "setitem", "take_along_axis", "put_along_axis", "where_branches"}
+# in-place functions: index of the destination argument
+_INPLACE = {"setitem": 0, "index_add": 0, "put_along_axis": 0}
+_NP_NAME = {"index_add": None, "getitem": None, "setitem": None, "max": "max", "min": "min"}
+
+COMPUTE = [
+    "absolute", "negative", "sign", "ceil", "floor", "sin", "cos", "tan", "sinh", "cosh", "tanh", "exp", "log", "sqrt",
+    "logical_not", "invert", "isnan", "add", "subtract", "multiply", "true_divide", "floor_divide", "mod", "power", "maximum",
+    "minimum", "equal", "not_equal", "less", "less_equal", "greater", "greater_equal", "logical_and", "logical_or", "logical_xor",
+    "where", "clip", "sum", "prod", "max", "min", "any", "all", "argmax", "argmin", "mean", "std", "matmul", "dot", "tensordot",
+    "concatenate", "stack", "tile", "repeat", "split", "take_along_axis", "put_along_axis", "index_add", "isin", "getitem", "setitem",
+    "nonzero", "flatnonzero", "argwhere",
+]
+
+
+def is_narrow_dtype(dt) -> bool:
+    return dt is not None and np.dtype(dt) in _WIDE
+
+
+def install(ns: dict):
+    """Wrap the computing functions of minidiff_amd.ndarray (its module globals `ns`)."""
+    DeviceArray = ns["DeviceArray"]
+
+    def has_narrow(x) -> bool:
+        if type(x) is DeviceArray:
+            return x._code >= NARROW_CODE_MIN
+        if isinstance(x, (np.generic, np.ndarray)):
+            return x.dtype in _WIDE
+        if isinstance(x, (list, tuple)):
+            for y in x:
+                if has_narrow(y):
+                    return True
+        return False
+
+    def any_narrow(args, kw) -> bool:
+        for x in args:
+            if has_narrow(x):
+                return True
+        if kw:
+            for k, v in kw.items():
+                if k == "dtype":
+                    if v is not None and is_narrow_dtype(v):
+                        return True
+                elif has_narrow(v):
+                    return True
+        return False
+
+    convert = ns["_convert"]
+
+    def dummy(x):
+        if type(x) is DeviceArray or isinstance(x, np.ndarray):
+            return np.ones(tuple(1 if s else 0 for s in x.shape), dtype=x.dtype)
+        if isinstance(x, (list, tuple)):
+            return type(x)(dummy(y) for y in x)
+        return x
+
+    def widen(x, name):
+        if type(x) is DeviceArray:
+            if x._code >= NARROW_CODE_MIN:
+                w = convert(x, _WIDE[x.dtype])
+                if x.dtype == _U64 and name not in _MOVERS and x.size and bool(ns["any"](ns["less"](w, 0)).item()):
+                    raise TypeError(f"uint64 values >= 2**63 are not supported by the MI355X backend in {name}()")
+                return w
+            return x
+        if isinstance(x, np.generic) and x.dtype in _WIDE:
+            if x.dtype == _U64 and int(x) >= 1 << 63:
+                raise TypeError(f"uint64 values >= 2**63 are not supported by the MI355X backend in {name}()")
+            return _WIDE[x.dtype].type(x)
+        if isinstance(x, np.ndarray) and x.dtype in _WIDE:
+            if x.dtype == _U64 and name not in _MOVERS and x.size and int(x.max()) >= 1 << 63:
+                raise TypeError(f"uint64 values >= 2**63 are not supported by the MI355X backend in {name}()")
+            return x.astype(_WIDE[x.dtype])
+        if isinstance(x, (list, tuple)):
+            return type(x)(widen(y, name) for y in x)
+        return x
+
+    def demote(res, ref):
+        """`res`: what the wide call returned; `ref`: what NumPy returned for the dummies (same structure)."""
+        if type(res) is DeviceArray:
+            rdt = ref.dtype if isinstance(ref, (np.ndarray, np.generic)) else None
+            if rdt is not None and rdt != res.dtype:
+                return convert(res, rdt)
+            return res
+        if isinstance(res, (list, tuple)) and isinstance(ref, (list, tuple)) and len(res) == len(ref):
+            return type(res)(demote(r, f) for r, f in zip(res, ref))
+        return res
+
+    def basic_key(key) -> bool:
+        if not isinstance(key, tuple):
+            key = (key,)
+        for k in key:
+            if not (k is None or k is Ellipsis or isinstance(k, (int, slice, np.integer))):
+                return False
+        return True
+
+    def call_numpy(name, npf, dargs, dkw):
+        if name == "getitem":
+            return np.zeros((0,), dtype=dargs[0].dtype)
+        if name == "index_add":
+            np.add.at(dargs[0], dummy_key(dargs[1]), dargs[2] if len(dargs) > 2 else dkw.get("b"))
+            return None
+        if name == "setitem":
+            dargs[0][dummy_key(dargs[1])] = dargs[2]
+            return None
+        return npf(*dargs, **dkw)
+
+    def dummy_key(key):
+        """A key that is valid on a one-element dummy: same index ARRAYS (dtype rules), positions zeroed."""
+        def one(k):
+            if isinstance(k, np.ndarray):
+                return np.zeros_like(k) if k.dtype != np.bool_ else np.ones_like(k)
+            if isinstance(k, (list, tuple)):
+                return type(k)(one(x) for x in k)
+            if isinstance(k, (int, np.integer)):
+                return 0
+            return k
+        return tuple(one(k) for k in key) if isinstance(key, tuple) else one(key)
+
+    def make(name, fn):
+        npf = getattr(np, _NP_NAME.get(name, name) or "zeros")
+
+        def wrapped(*args, **kw):
+            if not any_narrow(args, kw):
+                return fn(*args, **kw)
+            if name == "getitem" and basic_key(args[1]):
+                return fn(*args, **kw)          # a view: strides only, no kernel
+            # NumPy's own verdict on dtypes (and its exceptions) from one-element dummies
+            dargs = [dummy(a) for a in args]
+            dkw = {k: dummy(v) for k, v in kw.items()}
+            with np.errstate(all="ignore"):
+                ref = call_numpy(name, npf, dargs, dkw)
+            wargs = [widen(a, name) for a in args]
+            wkw = {k: (_WIDE[np.dtype(v)] if k == "dtype" and v is not None and is_narrow_dtype(v) else widen(v, name)) for k, v in kw.items()}
+            dest = _INPLACE.get(name)
+            if dest is not None:
+                target = args[dest]
+                fn(*wargs, **wkw)
+                if type(target) is DeviceArray and target._code >= NARROW_CODE_MIN:
+                    ns["_copy_into"](target, wargs[dest])     # the widened copy was updated: back into the narrow array
+                return None
+            return demote(fn(*wargs, **wkw), ref)
+
+        wrapped.__name__ = getattr(fn, "__name__", name)
+        wrapped.__doc__ = getattr(fn, "__doc__", None)
+        wrapped.__wrapped__ = fn
+        return wrapped
+
+    for name in COMPUTE:
+        if name in ns:
+            ns[name] = make(name, ns[name])
+
+    def inplace(ufunc, fn, a, b):
+        """a OP= b for a narrow `a` (or a wide `a` with a narrow `b`): NumPy's casting verdict from the dummies, the
+        arithmetic in the wide type, the result converted back into a's memory."""
+        da, db = dummy(a), dummy(b)
+        with np.errstate(all="ignore"):
+            ufunc(da, db, out=da)                   # raises NumPy's UFuncTypeError where NumPy would
+        res = fn(widen(a, ufunc.__name__), widen(b, ufunc.__name__))
+        ns["_copy_into"](a, res)
+        return a
+
+    ns["_narrow_inplace"] = inplace
+    ns["_any_narrow"] = any_narrow

@@ -29,6 +29,7 @@ import numpy as np
 
 from . import _capi
 from . import lazy as _lz
+from . import narrow as _narrow
 from ._capi import ArrayDesc, IndexPlan, MAX_NDIM
 
 # Lazy fusion of elementwise chains (minidiff_amd/lazy.py) is opt-in; eager —
@@ -56,8 +57,14 @@ _DTYPE_CODES = {
     np.dtype(np.int64): _capi.I64,
     np.dtype(np.float32): _capi.F32,
     np.dtype(np.float64): _capi.F64,
+    # storage-only dtypes (reference table numpy.py:188-200): held, moved and converted on the device; arithmetic on them is
+    # promote -> wide kernel -> demote (minidiff_amd/narrow.py). Any compute entry point handed one of these codes refuses it.
+    np.dtype(np.int8): _capi.I8, np.dtype(np.int16): _capi.I16,
+    np.dtype(np.uint8): _capi.U8, np.dtype(np.uint16): _capi.U16, np.dtype(np.uint32): _capi.U32, np.dtype(np.uint64): _capi.U64,
+    np.dtype(np.float16): _capi.F16,
 }
 _FLOAT_CODES = (_capi.F32, _capi.F64)
+_NARROW_MIN = _capi.I8   # codes >= this: storage-only
 
 
 def dtype_code(dt) -> int:
@@ -68,7 +75,7 @@ def dtype_code(dt) -> int:
     dt = np.dtype(dt)
     code = _DTYPE_CODES.get(dt)
     if code is None:
-        raise TypeError(f"dtype {dt} is not supported by the MI355X backend (bool, int32, int64, float32, float64)")
+        raise TypeError(f"dtype {dt} is not supported by the MI355X backend (bool, int8/16/32/64, uint8/16/32/64, float16/32/64)")
     return code
 
 
@@ -325,7 +332,7 @@ class DeviceArray:
         dtype_code(arr.dtype)
         host = arr if arr.flags.c_contiguous else np.array(arr, order="C")  # (ascontiguousarray would promote 0-d to 1-d)
         out = DeviceArray.empty(host.shape, host.dtype)
-        if host.size == 1:
+        if host.size == 1 and out._code < _NARROW_MIN:
             # one element (a wrapped Python scalar): a fill launch instead of an upload — no stream
             # synchronisation, and it stays capturable into a graph (graph.py)
             _fill(out, host.reshape(()).item())
@@ -599,15 +606,17 @@ class DeviceArray:
     def __xor__(self, o): return logical_xor(self, o) if self.dtype == np.bool_ else NotImplemented
 
     # in-place forms act on this array's memory (minidiff/tensor.py:269-362)
-    def __iadd__(self, o): return _binary(np.add, _capi.B_ADD, self, o, out=self)
-    def __isub__(self, o): return _binary(np.subtract, _capi.B_SUB, self, o, out=self)
-    def __imul__(self, o): return _binary(np.multiply, _capi.B_MUL, self, o, out=self)
-    def __itruediv__(self, o): return _binary(np.true_divide, _capi.B_TRUE_DIV, self, o, out=self)
-    def __ifloordiv__(self, o): return _binary(np.floor_divide, _capi.B_FLOOR_DIV, self, o, out=self)
-    def __imod__(self, o): return _binary(np.remainder, _capi.B_MOD, self, o, out=self)
-    def __ipow__(self, o): return _binary(np.power, _capi.B_POW, self, o, out=self)
+    def __iadd__(self, o): return _inplace(np.add, _capi.B_ADD, add, self, o)
+    def __isub__(self, o): return _inplace(np.subtract, _capi.B_SUB, subtract, self, o)
+    def __imul__(self, o): return _inplace(np.multiply, _capi.B_MUL, multiply, self, o)
+    def __itruediv__(self, o): return _inplace(np.true_divide, _capi.B_TRUE_DIV, true_divide, self, o)
+    def __ifloordiv__(self, o): return _inplace(np.floor_divide, _capi.B_FLOOR_DIV, floor_divide, self, o)
+    def __imod__(self, o): return _inplace(np.remainder, _capi.B_MOD, mod, self, o)
+    def __ipow__(self, o): return _inplace(np.power, _capi.B_POW, power, self, o)
 
     def __imatmul__(self, o):
+        if _any_narrow((self, o), None):
+            return _narrow_inplace(np.matmul, matmul, self, o)
         res = matmul(self, o)
         if res.shape != self.shape:
             raise ValueError(f"inplace matrix multiplication requires the result shape {res.shape} to equal {self.shape}")
@@ -619,6 +628,13 @@ class DeviceArray:
 
     def __setitem__(self, key, value):
         setitem(self, key, value)
+
+
+def _inplace(ufunc, code, fn, a, b):
+    """a OP= b: the wide types take the in-place kernel; a storage-only dtype on either side goes promote -> compute -> convert back."""
+    if a._code >= _NARROW_MIN or _any_narrow((b,), None):
+        return _narrow_inplace(ufunc, fn, a, b)
+    return _binary(ufunc, code, a, b, out=a)
 
 
 # =============================================================================
@@ -836,6 +852,13 @@ def _binary(ufunc, code, a, b, out=None):
         a_arr = True
     loop = _resolve(ufunc, (_kind_key(a), _kind_key(b)))
     cdt, odt = loop[0], loop[2]
+    if (cdt in _narrow._WIDE or odt in _narrow._WIDE) and out is None:
+        # NumPy resolves this pair to a storage-only loop (bool / bool -> float16, bool ** bool -> int8): the same arithmetic
+        # in the wide type, converted once (narrow.py)
+        wa = astype(a, _narrow._WIDE.get(loop[0], loop[0])) if a_arr else a
+        wb = astype(b, _narrow._WIDE.get(loop[1], loop[1])) if b_arr else b
+        res = _binary(ufunc, code, wa, wb)
+        return res if res.dtype == odt else _convert(res, odt)
     if code == _capi.B_POW and cdt.kind == "i":
         _check_int_power(b)
     if a_arr and b_arr:
@@ -914,6 +937,10 @@ def _unary(ufunc, code, x):
         for dt in loop:
             dtype_code(dt)
         _RESOLVE_CACHE[key] = loop
+    if loop[1] in _narrow._WIDE or loop[0] in _narrow._WIDE:
+        # (sin(bool array): NumPy answers in float16 — computed in float32, rounded once, as NumPy's own half loops do)
+        res = _unary(ufunc, code, astype(x, _narrow._WIDE.get(loop[0], loop[0])))
+        return res if res.dtype == loop[1] else _convert(res, loop[1])
     if _LAZY and code != _capi.U_INVERT and x.size > 0:
         pcdt = _FLOAT_DT.get(loop[0])
         if pcdt is not None and (loop[1] == loop[0] or loop[1] == np.bool_) and x.dtype.kind in "fb" or \
@@ -955,6 +982,13 @@ def _unalias(x, out: "DeviceArray"):
 def _copy_into(dst: DeviceArray, src, shape=None):
     """dst[...] = src with broadcasting and dtype conversion (unary COPY kernel)."""
     _before_write(dst)
+    if dst._code >= _NARROW_MIN or (isinstance(src, DeviceArray) and src._code >= _NARROW_MIN) or (isinstance(src, np.generic) and src.dtype in _narrow._WIDE):
+        if not isinstance(src, DeviceArray):     # a scalar: through a 0-d array of its own (or the default) type
+            h = np.asarray(src)
+            src = DeviceArray.from_numpy(h if h.dtype.kind != "O" else np.asarray(src, dtype=np.float64))
+        src = _unalias(src, dst)
+        _lib().convert(src.desc(dst.shape), dst.desc())
+        return
     if isinstance(src, DeviceArray):
         src = _unalias(src, dst)
         sd = src.desc(dst.shape)
@@ -971,7 +1005,7 @@ def _copy_into(dst: DeviceArray, src, shape=None):
 
 def _fill(dst: DeviceArray, value):
     _before_write(dst)
-    if isinstance(value, DeviceArray):
+    if isinstance(value, DeviceArray) or dst._code >= _NARROW_MIN:
         _copy_into(dst, value)
         return
     if isinstance(value, np.generic):
@@ -1096,14 +1130,27 @@ def astype(a, dtype, copy=True, **_):
     if dtype == a.dtype and not copy:
         return a
     res = DeviceArray.empty(a.shape, dtype)
-    _lib().unary(_capi.U_COPY, a.desc(), res.desc())
+    if a._code >= _NARROW_MIN or res._code >= _NARROW_MIN:
+        _lib().convert(a.desc(), res.desc())
+    else:
+        _lib().unary(_capi.U_COPY, a.desc(), res.desc())
+    return res
+
+
+def _convert(a: "DeviceArray", dtype) -> "DeviceArray":
+    """A new C-contiguous array of `dtype` with a's values converted (any pair of the 12 dtypes: mdhip_convert)."""
+    res = DeviceArray.empty(a.shape, dtype)
+    _lib().convert(a.desc(), res.desc())
     return res
 
 
 def copy(a, order="K", **_):
     a = asarray(a)
     res = DeviceArray.empty(a.shape, a.dtype)
-    _lib().unary(_capi.U_COPY, a.desc(), res.desc())
+    if a._code >= _NARROW_MIN:
+        _lib().convert(a.desc(), res.desc())
+    else:
+        _lib().unary(_capi.U_COPY, a.desc(), res.desc())
     return res
 
 
@@ -2503,3 +2550,8 @@ def random_permutation(n: int):
     if n:
         _lib().random_permutation(_DeviceRng.seed, _rng_take(2 * n), res.desc())
     return res
+
+
+# storage-only dtypes (float16, int8/16, uint8/16/32/64): the computing functions above are wrapped so that a call with such an
+# operand runs promote -> wide kernel -> demote; calls on the compute dtypes pay one flag test per argument (narrow.py)
+_narrow.install(globals())

@@ -210,6 +210,23 @@ int mdhip_graph_launch(void *) { return md_fail(MDHIP_ERUNTIME, "the CPU test do
 int mdhip_graph_destroy(void *) { return MDHIP_OK; }
 
 int mdhip_unary(int op, const mdhip_array *x, const mdhip_array *out) { return md_unary_dispatch<HostExec>(op, x, out); }
+int mdhip_convert(const mdhip_array *x, const mdhip_array *out) {
+  MD_TRY(md_check_any_array(x, "convert x"));
+  MD_TRY(md_check_any_array(out, "convert out"));
+  MdIter it;
+  const mdhip_array *ops[2] = {x, out};
+  MD_TRY(md_build_iter(&it, 2, ops, out));
+  int64_t offs[MD_MAX_OPS];
+  for (int64_t i = 0; i < it.total; ++i) {
+    md_iter_offsets(it, i, offs);
+    switch (md_dtype_carrier(x->dtype)) {
+      case 2: md_store_any<double>(out->data, out->dtype, offs[1], md_load_any<double>(x->data, x->dtype, offs[0])); break;
+      case 1: md_store_any<uint64_t>(out->data, out->dtype, offs[1], md_load_any<uint64_t>(x->data, x->dtype, offs[0])); break;
+      default: md_store_any<int64_t>(out->data, out->dtype, offs[1], md_load_any<int64_t>(x->data, x->dtype, offs[0])); break;
+    }
+  }
+  return MDHIP_OK;
+}
 int mdhip_binary(int op, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out, int cdt) {
   return md_binary_dispatch<HostExec>(op, a, b, out, cdt);
 }

@@ -408,7 +408,7 @@ def case_errors(nd):
     for fn, exc in ((lambda: nd.add(x, nd.asarray(np.zeros((4,)))), ValueError),
                     (lambda: nd.sum(x, axis=5), (ValueError, IndexError)),
                     (lambda: nd.reshape(x, (4, 2)), ValueError),
-                    (lambda: nd.asarray(np.zeros(3, dtype=np.float16)), TypeError),
+                    (lambda: nd.asarray(np.zeros(3, dtype=np.complex64)), TypeError),
                     (lambda: nd.subtract(nd.asarray(np.array([True])), nd.asarray(np.array([False]))), TypeError),
                     (lambda: nd.transpose(x, (0, 0)), ValueError),
                     (lambda: x[2], IndexError)):

@@ -121,8 +121,6 @@ def one_case(rng, big):
                 return
             if name == "sign" and h.dtype == np.bool_:
                 return
-            if name in ("sin", "cos", "tanh", "exp", "sqrt", "ceil", "floor") and h.dtype == np.bool_:
-                return  # NumPy answers in float16, which the backend does not carry
             close(getattr(nd, name)(d), getattr(np, name)(h), f"{name}{h.shape}{h.dtype}")
         elif kind == "binary":
             name = str(rng.choice(BINARY))
@@ -142,16 +140,12 @@ def one_case(rng, big):
                 if np.asarray(h).dtype.kind == "f":
                     h = np.clip(np.nan_to_num(h, nan=1.0, posinf=2.0, neginf=-2.0), -4, 4).astype(h.dtype)
                     d = nd.asarray(h)
-                if np.asarray(h).dtype == np.bool_ and np.asarray(h2).dtype == np.bool_:
-                    return  # NumPy answers in int8
             if name in ("subtract",) and (np.asarray(h).dtype == np.bool_ and np.asarray(h2).dtype == np.bool_):
                 return
             if rng.random() < 0.5:
                 h, h2, d, d2 = h2, h, d2, d
             if not isinstance(d, nd.DeviceArray) and not isinstance(d2, nd.DeviceArray):
                 return
-            if name in ("floor_divide", "mod", "true_divide") and np.asarray(h).dtype == np.bool_ and np.asarray(h2).dtype == np.bool_:
-                return  # int8 / float16 answers
             try:
                 exp = getattr(np, name)(h, h2)
             except (ValueError, TypeError) as e:   # e.g. integers to negative integer powers

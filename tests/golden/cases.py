@@ -97,6 +97,27 @@ _add(_case("argmax_keepdims", [_r(72, (3, 4, 5))], lambda md, x: md.argmax(x, ax
 _add(_case("any_all", [_r(73, (3, 4)) > 0], lambda md, x: md.logical_and(md.any(x), md.all(x)), grads=[False],
            dtypes=("bool",)))
 
+# storage-only dtypes of the reference table (backend/numpy.py:188-200): float16, int8/16, uint8/16/32 — integers bit-exact
+# (NumPy's wrap-around included), float16 within its own precision
+_NI = ("int8", "int16", "uint8", "uint16", "uint32")
+_ia = np.array([[100, -100, 27, -128, 127, 5], [3, -7, 90, 64, -64, 1]])
+_ib = np.array([[3, 2, 9, 1, 1, -4], [50, 13, 2, 2, -3, 120]])
+_add(_case("narrow_int_wrap", [_ia, _ib], lambda md, x, y: x * y + x - y, grads=[False, False], dtypes=_NI))
+_add(_case("narrow_int_divmod", [np.array([7, 100, 5, 120, 0, 9]), np.array([2, 7, 3, 11, 4, 5])],
+           lambda md, x, y: md.floor_divide(x, y) * 10 + md.mod(x, y) + md.power(y, 2), grads=[False, False], dtypes=_NI))
+_add(_case("narrow_int_where_max", [_ia, _ib], lambda md, x, y: md.where(x > y, x, y) - md.max(x, axis=(1,), keepdims=True),
+           grads=[False, False], dtypes=_NI))
+_add(_case("narrow_int_sum", [_ia], lambda md, x: md.sum(x, axis=(0,)), grads=[False], dtypes=_NI))
+_add(_case("narrow_int_true_divide", [_ia, _ib], lambda md, x, y: md.true_divide(x, y), grads=[False, False], dtypes=("int8", "uint8", "int16")))
+_add(_case("narrow_int_mixed", [_ia.astype(np.int8), _ib.astype(np.int64)], lambda md, x, y: x + y, grads=[False, False], dtypes=("asis",)))
+_add(_case("narrow_int_getitem", [np.arange(24).reshape(4, 6), np.array([3, 0, 3, 1])], lambda md, x, i: x[i], grads=[False, False],
+           dtypes=("int16", "uint8")))
+_add(_case("narrow_f16_chain", [_r(80, (3, 5)), _r(81, (3, 5))], lambda md, x, y: md.sin(x) * y + x ** 2, dtypes=("float16",)))
+_add(_case("narrow_f16_broadcast_sum", [_r(82, (4, 6)), _r(83, (6,))], lambda md, x, b: md.sum(md.where(x + b > 0, x + b, 0), axis=(0,)),
+           dtypes=("float16",)))
+_add(_case("narrow_f16_matmul", [_r(84, (4, 8)), _r(85, (8, 3)) / 4], lambda md, X, W: X @ W, dtypes=("float16",)))
+_add(_case("narrow_f16_getitem", [_r(86, (5, 4)), np.array([4, 1, 1, 0])], lambda md, x, i: x[i], grads=[True, False], dtypes=("float16",)))
+
 
 def loss_of(md, out):
     """tests/test_ops.py:42-45 — half squared distance to zero."""
