@@ -159,6 +159,8 @@ def install(ns: dict):
             # NumPy's own verdict on dtypes (and its exceptions) from one-element dummies
             dargs = [dummy(a) for a in args]
             dkw = {k: dummy(v) for k, v in kw.items()}
+            if name in ("take_along_axis", "put_along_axis") and len(dargs) > 1 and isinstance(dargs[1], np.ndarray):
+                dargs[1] = np.zeros_like(dargs[1])      # positions must exist in a one-element dummy
             with np.errstate(all="ignore"):
                 ref = call_numpy(name, npf, dargs, dkw)
             wargs = [widen(a, name) for a in args]
