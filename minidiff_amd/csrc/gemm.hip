@@ -42,6 +42,7 @@
 #include "md_hip.h"
 
 extern "C" int mdhip_alloc(size_t, void **);
+extern "C" int mdhip_unary(int, const mdhip_array *, const mdhip_array *);
 extern "C" int mdhip_free(void *);
 
 namespace {
@@ -73,6 +74,10 @@ struct GemmArgs {
   unsigned long long *stamp;
   // ragged direct-to-LDS kernels: 16 B of zeros in device memory — what a DMA lane fetches for a position outside the operand
   const float *zero;
+  // host side only: the row-contiguous operand A (B) sits in a buffer of OURS whose rows are padded to a multiple of four
+  // elements (repacked copy, HipExec::gemm): a 16-B piece that straddles the M (N) edge reads the padding, which only feeds
+  // output rows (columns) outside C — so M (N) need not be a multiple of 4 for the direct-to-LDS kernels
+  int pad_m, pad_n;
 };
 
 // Tile loaders for a ROWS x BK operand tile, NT threads, 16 B per thread per pass.
@@ -993,7 +998,7 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
     if constexpr (!A_KC && !B_KC && SCHED != 0 && BK >= 32) {
       // ragged TN: still direct to LDS when every 16-B piece lies wholly inside or outside the operands (M, N multiples of 4)
       const char *e = getenv("MDHIP_GEMM_GLDS");
-      ragged_dma = edge && aligned && (e ? atoi(e) != 0 : true) && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp && ga.M % 4 == 0 && ga.N % 4 == 0 && ga.a_ks > 0 && ga.b_ks > 0 &&
+      ragged_dma = edge && aligned && (e ? atoi(e) != 0 : true) && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp && (ga.M % 4 == 0 || ga.pad_m) && (ga.N % 4 == 0 || ga.pad_n) && ga.a_ks > 0 && ga.b_ks > 0 &&
                    (ga.zero = md_zero_block()) != nullptr;
       if (ragged_dma) {
         // whole k-tiles on the 128-row tiles: predicated lanes + scalar-base addresses (4100 x 4096 x 4100: 104-108 -> 112-124 TFLOP/s);
@@ -1111,7 +1116,7 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
   const bool dma_ok = (e ? atoi(e) != 0 : true) && !edge && !ga.stamp && (A_KC ? ga.a_ks == 1 : ga.a_ms == 1) && (B_KC ? ga.b_ks == 1 : ga.b_ns == 1) &&
                       (A_KC || !B_KC) &&   // (A row-contiguous with B k-contiguous — "TT" — has no such kernel)
                       // sizes the tiles do not divide: every 16-B piece must lie wholly inside or outside its operand
-                      ((A_KC || B_KC) ? ga.K % 4 == 0 : true) && (A_KC || ga.M % 4 == 0) && (B_KC || ga.N % 4 == 0);
+                      ((A_KC || B_KC) ? ga.K % 4 == 0 : true) && (A_KC || ga.M % 4 == 0 || ga.pad_m) && (B_KC || ga.N % 4 == 0 || ga.pad_n);
   const int cfg = pick_cfg(ga, batch, !A_KC && !B_KC, dma_ok);
   if constexpr (A_KC) {
     if (dma_ok) {
@@ -1357,10 +1362,51 @@ struct HipExec {
         bool edge = !al16(g.a) || !al16(g.b);
         // the vector axis' partner stride must keep rows 16-B aligned
         edge = edge || ((A_KC ? g.a_ms : g.a_ks) & 3) || ((B_KC ? g.b_ns : g.b_ks) & 3) || (g.a_bs & 3) || (g.b_bs & 3);
-        if (A_KC && B_KC) return launch_mfma<true, true>(ga, g.batch, edge);
-        if (A_KC && !B_KC) return launch_mfma<true, false>(ga, g.batch, edge);
-        if (!A_KC && B_KC) return launch_mfma<false, true>(ga, g.batch, edge);
-        return launch_mfma<false, false>(ga, g.batch, edge);
+        // Misaligned operands of a LARGE product (an odd leading dimension: x.T of a 4097-column matrix; a view that starts
+        // off a 16-B boundary): one strided copy into an aligned buffer whose rows are padded to a multiple of four elements,
+        // then the direct-to-LDS kernels — 4097 x 4096 x 4100 TN ran at 71 TFLOP/s on the register-staged edge kernel
+        // (DESIGN §9.1). Worth it when the product is >= 50x the copy (2 M N K flop against 8 bytes per copied element).
+        void *tmp_a = nullptr, *tmp_b = nullptr;
+        static const bool repack_on = [] { const char *e = getenv("MDHIP_GEMM_REPACK"); return !(e && e[0] == '0'); }();
+        if (edge && repack_on && g.batch == 1 && (A_KC || B_KC ? g.K % 4 == 0 : true) && g.M >= 256 && g.N >= 256 && g.K >= 256 && !ga.stamp) {
+          const bool a_bad = !al16(g.a) || ((A_KC ? g.a_ms : g.a_ks) & 3), b_bad = !al16(g.b) || ((B_KC ? g.b_ns : g.b_ks) & 3);
+          auto repack = [](const float *src, int64_t rows, int64_t cols, int64_t row_stride, void **tmp, int64_t *ld) -> int {
+            // rows x cols, unit stride along cols -> rows x ld (ld = cols rounded up to 4; the padding stays unwritten)
+            *ld = (cols + 3) & ~(int64_t)3;
+            MD_TRY(mdhip_alloc((size_t)(rows * *ld) * sizeof(float), tmp));
+            mdhip_array sd{}, dd{};
+            sd.data = const_cast<float *>(src); sd.dtype = MDHIP_F32; sd.ndim = 2; sd.shape[0] = rows; sd.shape[1] = cols; sd.strides[0] = row_stride; sd.strides[1] = 1;
+            dd = sd; dd.data = *tmp; dd.strides[0] = *ld;
+            return mdhip_unary(MDHIP_U_COPY, &sd, &dd);
+          };
+          int rc = MDHIP_OK;
+          if (a_bad) {
+            int64_t ld;
+            if (A_KC) { rc = repack(ga.A, g.M, g.K, g.a_ms, &tmp_a, &ld); ga.a_ms = ld; }
+            else { rc = repack(ga.A, g.K, g.M, g.a_ks, &tmp_a, &ld); ga.a_ks = ld; ga.pad_m = 1; }
+            if (rc == MDHIP_OK) ga.A = (const float *)tmp_a;
+          }
+          if (rc == MDHIP_OK && b_bad) {
+            int64_t ld;
+            if (B_KC) { rc = repack(ga.B, g.N, g.K, g.b_ns, &tmp_b, &ld); ga.b_ns = ld; }
+            else { rc = repack(ga.B, g.K, g.N, g.b_ks, &tmp_b, &ld); ga.b_ks = ld; ga.pad_n = 1; }
+            if (rc == MDHIP_OK) ga.B = (const float *)tmp_b;
+          }
+          if (rc != MDHIP_OK) {
+            if (tmp_a) mdhip_free(tmp_a);
+            if (tmp_b) mdhip_free(tmp_b);
+            return rc;
+          }
+          edge = false;
+        }
+        int rc;
+        if (A_KC && B_KC) rc = launch_mfma<true, true>(ga, g.batch, edge);
+        else if (A_KC && !B_KC) rc = launch_mfma<true, false>(ga, g.batch, edge);
+        else if (!A_KC && B_KC) rc = launch_mfma<false, true>(ga, g.batch, edge);
+        else rc = launch_mfma<false, false>(ga, g.batch, edge);
+        if (tmp_a) mdhip_free(tmp_a);   // stream-ordered: the next user of the block runs after the product
+        if (tmp_b) mdhip_free(tmp_b);
+        return rc;
       }
     }
     if constexpr (md_same<T, double>::value) {

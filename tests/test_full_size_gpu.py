@@ -273,6 +273,45 @@ def test_direct_to_lds_gemm_random_aligned_shapes(lib, on_gpu):
         nd.set_lazy(prev)
 
 
+def test_misaligned_operands_of_large_products_are_repacked(lib, on_gpu):
+    """Odd leading dimensions (x.T of a matrix with an odd column count) and views that start off a 16-byte boundary: large
+    products copy such an operand once into an aligned, row-padded buffer and take the direct-to-LDS kernels (gemm.hip,
+    HipExec::gemm); the padding must never reach C. Integer-valued operands: the products must EQUAL NumPy's, in every layout,
+    with the repack on and off."""
+    assert on_gpu
+    import os
+    from minidiff_amd import ndarray as nd
+    rng = np.random.default_rng(4097)
+    prev = nd.set_lazy(False)
+    try:
+        for (M, K, N) in ((1027, 512, 516), (513, 260, 1031), (771, 256, 771)):
+            for lay in ("NN", "NT", "TN", "TT"):
+                for off in (0, 1, 3):
+                    def make(rows, cols, transposed):
+                        r, c = (cols, rows) if transposed else (rows, cols)
+                        big = rng.integers(-3, 4, (r, c + off)).astype(np.float32)     # odd row stride and / or an offset start
+                        h, d = big[:, off:], nd.asarray(big)[:, off:]
+                        return (h.T, d.T) if transposed else (h, d)
+                    (ha, da), (hb, db) = make(M, K, lay[0] == "T"), make(K, N, lay[1] == "T")
+                    ref = np.matmul(ha.astype(np.float64), hb.astype(np.float64))
+                    for flag in ("1", "0"):
+                        os.environ["MDHIP_GEMM_REPACK"] = flag      # (read once per process: '0' only matters if it was set before the first product)
+                        got = nd.matmul(da, db).get()
+                        assert np.array_equal(got, ref), (M, K, N, lay, off, flag)
+        os.environ.pop("MDHIP_GEMM_REPACK", None)
+        # the shape DESIGN §9.1 quotes, TN with an odd M: result against float64
+        M, K, N = 4097, 4096, 4100
+        a = rng.standard_normal((K, M), dtype=np.float32)
+        b = rng.standard_normal((K, N), dtype=np.float32)
+        got = nd.matmul(nd.asarray(a).T, nd.asarray(b)).get()
+        ref = a.T.astype(np.float64)[:64] @ b.astype(np.float64)
+        assert _rel(got[:64], ref) < 5e-6
+        ref = a.T.astype(np.float64)[-33:] @ b.astype(np.float64)
+        assert _rel(got[-33:], ref) < 5e-6
+    finally:
+        nd.set_lazy(prev)
+
+
 def test_gemm_whole_tile_shapes_with_unusual_strides(lib, on_gpu):
     """Whole-tile shapes whose operands are flipped (negative strides), broadcast (stride 0) or every-other-row views: the
     direct-to-LDS launchers must either take them correctly or leave them to the register-staged kernel — exact on integers."""
