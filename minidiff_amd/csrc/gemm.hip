@@ -1321,6 +1321,118 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f64_mfma(GemmArgs64 g) {
     }
 }
 
+// ---- float64 TN on the direct-to-LDS scheme (round 3) -------------------------------------------------------------------
+// Same idea as k_gemm_f32_tn_glds: `global_load_lds_dwordx4` moves 64 lanes x 16 B = 1 KiB = 128 doubles — ONE k-row of a
+// 128-row tile — straight into LDS (no staging registers, no ds_write), one k-tile ahead, two separate buffers per operand with
+// the buffer fixed at compile time (loop unrolled by two). 128 x 128 x 16 tiles, four waves (wave tile 64 x 64 = 4 x 4 MFMAs
+// of v_mfma_f64_16x16x4_f64 per k-step, 128 accumulator registers), two blocks per CU (72 KiB of LDS each). k-rows sit
+// 1152 B apart (pad 128 B: the four k of a fragment land on different banks) -> a fragment is one ds_read_b64 of S[k][row].
+// Addresses: wave-uniform base (opaque to the optimiser: md_opaque_uniform) + loop-invariant 32-bit lane offset -> the DMA's
+// `vN, s[base]` form (checked with scripts/isa_check.py: 16 / 16 per two k-tiles, no ds_write, no vmcnt(0) drain).
+// Only the TN layout (both operands row-contiguous: the weight gradient A^T G): 4096^3 72.5-72.9 -> 73.4-75.5 TFLOP/s of 78.6.
+// The k-contiguous image (16 rows x 8 k per piece, as in k_gemm_f32_kc_glds) was built and measured too: NN 67-70, NT 62-64
+// against 73-74 for the register-staged kernel — a piece brings 64 B per row, half a cache line per DMA lane group — so NN / NT
+// (and every ragged or unaligned shape) stay on k_gemm_f64_mfma (profiles/r3_gemm_f64.log).
+constexpr int F64_TILE_LD = 128 + 16;   // doubles between the k-rows of an operand image
+// k-row p (0..15) of a 128-row x 16-k operand tile whose first k is k0; `base` = operand + first row of the tile (+ batch)
+__device__ __forceinline__ void glds64_krow(const double *base, int64_t ks, int64_t k0, double *S, int p, uint32_t lane_off) {
+  const char *ub = md_opaque_uniform(reinterpret_cast<const char *>(base + (k0 + p) * ks));
+  asm("" : "+v"(lane_off) : "s"((int)k0));   // (keeps the offset's zero-extension next to the DMA: see glds_tile_pass_u)
+  __builtin_amdgcn_global_load_lds((md_gbl_void *)(ub + lane_off), (md_lds_void *)(S + p * F64_TILE_LD), 16, 0, 0);
+}
+
+__global__ void __launch_bounds__(256, 2) k_gemm_f64_tn_glds(GemmArgs64 g) {
+  constexpr int BM = 128, BN = 128, BK = 16, WTM = 4, WTN = 4;
+  __shared__ __attribute__((aligned(16))) double A0[BK * F64_TILE_LD];
+  __shared__ __attribute__((aligned(16))) double A1[BK * F64_TILE_LD];
+  __shared__ __attribute__((aligned(16))) double B0[BK * F64_TILE_LD];
+  __shared__ __attribute__((aligned(16))) double B1[BK * F64_TILE_LD];
+  const int nblk = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // XCD-aware tile order
+  const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t bz = blockIdx.z;
+  const double *A = g.A + bz * g.a_bs + m0;
+  const double *B = g.B + bz * g.b_bs + n0;
+  double *C = g.C + bz * g.c_bs;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l16 = lane & 15, h = lane >> 4;
+  const uint32_t lo = (uint32_t)(lane * 16);
+
+  f64x4 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+
+  const int64_t nk = g.K / BK;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    glds64_krow(A, g.a_ks, 0, A0, i * 4 + wave, lo);
+    glds64_krow(B, g.b_ks, 0, B0, i * 4 + wave, lo);
+  }
+  __syncthreads();
+
+  double fa[2][WTM], fb[2][WTN];
+  // fragment of k-step s: lane (l16, h) supplies k = 4 s + h
+#define MD_F64_READ(BUF, s, c)                                                                                                     \
+  {                                                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < WTM; ++i) fa[c][i] = ((BUF) ? A1 : A0)[(4 * (s) + h) * F64_TILE_LD + wm * 64 + i * 16 + l16]; \
+    _Pragma("unroll") for (int j = 0; j < WTN; ++j) fb[c][j] = ((BUF) ? B1 : B0)[(4 * (s) + h) * F64_TILE_LD + wn * 64 + j * 16 + l16]; \
+  }
+  MD_F64_READ(0, 0, 0)
+  auto ktile = [&](auto curc, int64_t kn) {
+    constexpr int CUR = decltype(curc)::value;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int c = s & 1;
+      if (s + 1 < 4) MD_F64_READ(CUR, s + 1, c ^ 1)
+      if (s < 2) {   // the next tile's eight k-rows of this wave go out behind the first two k-steps
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          glds64_krow(A, g.a_ks, kn * BK, CUR ? A0 : A1, (2 * s + q) * 4 + wave, lo);
+          glds64_krow(B, g.b_ks, kn * BK, CUR ? B0 : B1, (2 * s + q) * 4 + wave, lo);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < WTM * WTN; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (m < 8 && s + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (s < 2 && m < 4) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+    }
+    __syncthreads();
+    MD_F64_READ(CUR ^ 1, 0, 0)
+  };
+  int64_t kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    ktile(MdInt<0>{}, kt + 1);
+    ktile(MdInt<1>{}, kt + 2 < nk ? kt + 2 : nk - 1);
+  }
+  if (kt < nk) ktile(MdInt<0>{}, nk - 1);
+#undef MD_F64_READ
+  // C/D of the f64 16x16 tile: col = lane & 15, row = (lane >> 4) + 4 r
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int64_t col = n0 + wn * 64 + j * 16 + l16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wm * 64 + i * 16 + h + 4 * r;
+        C[row * g.c_ms + col * g.c_ns] = acc[i][j][r];
+      }
+    }
+}
+
 template <int BM, int BN, bool A_KC, bool B_KC>
 static int launch_f64(GemmArgs64 ga, int64_t batch, bool edge) {
   constexpr int BK = 16;
@@ -1336,6 +1448,19 @@ static int launch_f64(GemmArgs64 ga, int64_t batch, bool edge) {
 template <bool A_KC, bool B_KC>
 static int launch_f64_pick(const GemmArgs64 &ga, int64_t batch, bool edge) {
   const int64_t t128 = ((ga.M + 127) / 128) * ((ga.N + 127) / 128) * batch;
+  if constexpr (!A_KC && !B_KC) {   // TN: both operands row-contiguous -> direct to LDS (k_gemm_f64_tn_glds)
+    const char *e = getenv("MDHIP_GEMM_GLDS");   // (read at every launch: A/B runs and the exactness tests)
+    const int64_t lim = 1ll << 25;
+    if ((e ? atoi(e) != 0 : true) && !edge && ga.a_ms == 1 && ga.b_ns == 1 && ga.M % 128 == 0 && ga.N % 128 == 0 && ga.K % 16 == 0 && ga.K >= 32 &&
+        t128 >= MD_NUM_CUS && ga.a_ks > 0 && ga.b_ks > 0 && ga.a_ks < lim && ga.b_ks < lim) {
+      GemmArgs64 g2 = ga;
+      g2.tiles_m = (int)(ga.M / 128);
+      g2.tiles_n = (int)(ga.N / 128);
+      dim3 grid((unsigned)(g2.tiles_m * g2.tiles_n), 1, (unsigned)batch);
+      k_gemm_f64_tn_glds<<<grid, 256, 0, md_stream()>>>(g2);
+      return MD_LAUNCH_CHECK("matmul(f64 mfma, direct-to-LDS)");
+    }
+  }
   if (t128 >= 2 * MD_NUM_CUS) return launch_f64<128, 128, A_KC, B_KC>(ga, batch, edge);
   return launch_f64<64, 64, A_KC, B_KC>(ga, batch, edge);
 }
