@@ -495,8 +495,10 @@ template <int V> struct MdInt { static constexpr int value = V; };
 
 // RAGGED: 0 whole tiles | 1 any ragged size (zero-filled lanes, 64-bit lane addresses) | 2 ragged M / N with K % BK == 0 (predicated lanes,
 // scalar-base addresses: the fast form)
-template <int BM, int BN, int BK, int WM, int WN, int RAGGED = 0>
+// (NBUF = 3: three LDS buffers, DMA two k-tiles ahead, counted vmcnt at the boundary — see k_gemm_f32_kc_glds)
+template <int BM, int BN, int BK, int WM, int WN, int RAGGED = 0, int NBUF = 2>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
+  static_assert(NBUF == 2 || (NBUF == 3 && RAGGED == 0), "three buffers: whole-tile kernel only");
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);
   constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT);
@@ -508,6 +510,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float A1[BK][BM];
   __shared__ __attribute__((aligned(16))) float B0[BK][BN];
   __shared__ __attribute__((aligned(16))) float B1[BK][BN];
+  __shared__ __attribute__((aligned(16))) float A2[NBUF == 3 ? BK : 1][BM];
+  __shared__ __attribute__((aligned(16))) float B2[NBUF == 3 ? BK : 1][BN];
 
   const int nblk = g.tiles_m * g.tiles_n;
   int bid = blockIdx.x;
@@ -545,6 +549,12 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
   for (int i = 0; i < PA; ++i) glds_tile_pass<BM, BK, NT, RAGGED != 0>(A, g.a_ks, m0, 0, &A0[0][0], i, g.M, g.K, g.zero);
 #pragma unroll
   for (int i = 0; i < PB; ++i) glds_tile_pass<BN, BK, NT, RAGGED != 0>(B, g.b_ks, n0, 0, &B0[0][0], i, g.N, g.K, g.zero);
+  if constexpr (NBUF == 3) {   // tile 1 into buffer 1 (K >= 2 k-tiles: the launcher checks)
+#pragma unroll
+    for (int i = 0; i < PA; ++i) glds_tile_pass<BM, BK, NT, false>(A, g.a_ks, m0, BK, &A1[0][0], i, g.M, g.K, g.zero);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) glds_tile_pass<BN, BK, NT, false>(B, g.b_ks, n0, BK, &B1[0][0], i, g.N, g.K, g.zero);
+  }
   const uint32_t la = glds_tile_lane_off<BM>(g.a_ks), lb = glds_tile_lane_off<BN>(g.b_ks);   // per-lane parts of the DMA addresses (loop-invariant)
   const int uw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float *wa = A + m0 + (int64_t)uw * (256 / BM) * g.a_ks, *wb = B + n0 + (int64_t)uw * (256 / BN) * g.b_ks;   // uniform parts
@@ -555,7 +565,13 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
     pra = m0 + (int64_t)((threadIdx.x & 63) % (BM / 4 > 64 ? 64 : BM / 4)) * 4 < g.M;
     prb = n0 + (int64_t)((threadIdx.x & 63) % (BN / 4 > 64 ? 64 : BN / 4)) * 4 < g.N;
   }
-  __syncthreads();
+  if constexpr (NBUF == 3) {
+    constexpr int NW8 = PA + PB;
+    __builtin_amdgcn_s_waitcnt((NW8 & 0xF) | ((NW8 >> 4) << 14) | (7 << 4) | (15 << 8));   // tile 0 landed; tile 1 may still fly
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __syncthreads();
+  }
 
   // fragments for TWO steps (4 k) per LDS instruction: rows 4p+h and 4p+2+h of the [k][row] image lie 2*ROWS floats apart, a
   // multiple of 64 dwords, so the two loads of a lane fuse into one ds_read2st64_b32 — half the LDS read instructions; MFMA t of
@@ -566,12 +582,12 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
 #define MD_TN_READ(BUF, p, c)                                                                                          \
   {                                                                                                                    \
     _Pragma("unroll") for (int i = 0; i < WTM; ++i) {                                                                  \
-      fa[c][i][0] = ((BUF) ? A1 : A0)[4 * (p) + h][am + i * 32];                                                       \
-      fa[c][i][1] = ((BUF) ? A1 : A0)[4 * (p) + 2 + h][am + i * 32];                                                   \
+      fa[c][i][0] = ((BUF) == 0 ? A0 : (BUF) == 1 ? A1 : A2)[4 * (p) + h][am + i * 32];                                                       \
+      fa[c][i][1] = ((BUF) == 0 ? A0 : (BUF) == 1 ? A1 : A2)[4 * (p) + 2 + h][am + i * 32];                                                   \
     }                                                                                                                  \
     _Pragma("unroll") for (int q = 0; q < WTN; ++q) {                                                                  \
-      fb[c][q][0] = ((BUF) ? B1 : B0)[4 * (p) + h][bn + q * 32];                                                       \
-      fb[c][q][1] = ((BUF) ? B1 : B0)[4 * (p) + 2 + h][bn + q * 32];                                                   \
+      fb[c][q][0] = ((BUF) == 0 ? B0 : (BUF) == 1 ? B1 : B2)[4 * (p) + h][bn + q * 32];                                                       \
+      fb[c][q][1] = ((BUF) == 0 ? B0 : (BUF) == 1 ? B1 : B2)[4 * (p) + 2 + h][bn + q * 32];                                                   \
     }                                                                                                                  \
   }
   MD_TN_READ(0, 0, 0)
@@ -589,14 +605,14 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
         for (int q = 0; q < PPS; ++q) {
           const int pi = sidx * PPS + q;
           if (pi < PA) {
-            if constexpr (RAGGED == 1) glds_tile_pass<BM, BK, NT, true>(A, g.a_ks, m0, kn * BK, CUR ? &A0[0][0] : &A1[0][0], pi, g.M, g.K, g.zero);
-            else if constexpr (RAGGED == 2) glds_tile_pass_u<BM, BK, NT, true>(wa, sa, kn * BK * g.a_ks, CUR ? &A0[0][0] : &A1[0][0], pi, la, pra);
-            else glds_tile_pass_u<BM, BK, NT>(wa, sa, kn * BK * g.a_ks, CUR ? &A0[0][0] : &A1[0][0], pi, la);
+            if constexpr (RAGGED == 1) glds_tile_pass<BM, BK, NT, true>(A, g.a_ks, m0, kn * BK, (NBUF == 2 ? (CUR ? &A0[0][0] : &A1[0][0]) : (CUR == 0 ? &A2[0][0] : CUR == 1 ? &A0[0][0] : &A1[0][0])), pi, g.M, g.K, g.zero);
+            else if constexpr (RAGGED == 2) glds_tile_pass_u<BM, BK, NT, true>(wa, sa, kn * BK * g.a_ks, (NBUF == 2 ? (CUR ? &A0[0][0] : &A1[0][0]) : (CUR == 0 ? &A2[0][0] : CUR == 1 ? &A0[0][0] : &A1[0][0])), pi, la, pra);
+            else glds_tile_pass_u<BM, BK, NT>(wa, sa, kn * BK * g.a_ks, (NBUF == 2 ? (CUR ? &A0[0][0] : &A1[0][0]) : (CUR == 0 ? &A2[0][0] : CUR == 1 ? &A0[0][0] : &A1[0][0])), pi, la);
             ++n_dma;
           } else if (pi < PA + PB) {
-            if constexpr (RAGGED == 1) glds_tile_pass<BN, BK, NT, true>(B, g.b_ks, n0, kn * BK, CUR ? &B0[0][0] : &B1[0][0], pi - PA, g.N, g.K, g.zero);
-            else if constexpr (RAGGED == 2) glds_tile_pass_u<BN, BK, NT, true>(wb, sb, kn * BK * g.b_ks, CUR ? &B0[0][0] : &B1[0][0], pi - PA, lb, prb);
-            else glds_tile_pass_u<BN, BK, NT>(wb, sb, kn * BK * g.b_ks, CUR ? &B0[0][0] : &B1[0][0], pi - PA, lb);
+            if constexpr (RAGGED == 1) glds_tile_pass<BN, BK, NT, true>(B, g.b_ks, n0, kn * BK, (NBUF == 2 ? (CUR ? &B0[0][0] : &B1[0][0]) : (CUR == 0 ? &B2[0][0] : CUR == 1 ? &B0[0][0] : &B1[0][0])), pi - PA, g.N, g.K, g.zero);
+            else if constexpr (RAGGED == 2) glds_tile_pass_u<BN, BK, NT, true>(wb, sb, kn * BK * g.b_ks, (NBUF == 2 ? (CUR ? &B0[0][0] : &B1[0][0]) : (CUR == 0 ? &B2[0][0] : CUR == 1 ? &B0[0][0] : &B1[0][0])), pi - PA, lb, prb);
+            else glds_tile_pass_u<BN, BK, NT>(wb, sb, kn * BK * g.b_ks, (NBUF == 2 ? (CUR ? &B0[0][0] : &B1[0][0]) : (CUR == 0 ? &B2[0][0] : CUR == 1 ? &B0[0][0] : &B1[0][0])), pi - PA, lb);
             ++n_dma;
           }
         }
@@ -614,16 +630,33 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_tn_glds(GemmArgs g) {
         }
       }
     }
-    __syncthreads();
-    MD_TN_READ(CUR ^ 1, 0, 0)
+    if constexpr (NBUF == 2) {
+      __syncthreads();
+      MD_TN_READ(CUR ^ 1, 0, 0)
+    } else {
+      constexpr int NW8 = PA + PB;   // (counted wait: the tile computed next is complete, the one just issued may still fly)
+      __builtin_amdgcn_s_waitcnt((NW8 & 0xF) | ((NW8 >> 4) << 14) | (7 << 4) | (15 << 8));
+      __builtin_amdgcn_s_barrier();
+      MD_TN_READ((CUR + 1) % 3, 0, 0)
+    }
   };
-#undef MD_TN_READ
   int64_t kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    ktile(MdInt<0>{}, kt + 1);
-    ktile(MdInt<1>{}, kt + 2 < nk ? kt + 2 : nk - 1);
+  if constexpr (NBUF == 2) {
+    for (; kt + 1 < nk; kt += 2) {
+      ktile(MdInt<0>{}, kt + 1);
+      ktile(MdInt<1>{}, kt + 2 < nk ? kt + 2 : nk - 1);
+    }
+    if (kt < nk) ktile(MdInt<0>{}, nk - 1);
+  } else {
+    for (; kt + 2 < nk; kt += 3) {
+      ktile(MdInt<0>{}, kt + 2);
+      ktile(MdInt<1>{}, kt + 3 < nk ? kt + 3 : nk - 1);
+      ktile(MdInt<2>{}, kt + 4 < nk ? kt + 4 : nk - 1);
+    }
+    if (kt < nk) ktile(MdInt<0>{}, nk - 1);
+    if (kt + 1 < nk) ktile(MdInt<1>{}, nk - 1);
   }
-  if (kt < nk) ktile(MdInt<0>{}, nk - 1);
+#undef MD_TN_READ
 
 #pragma unroll
   for (int i = 0; i < WTM; ++i)
@@ -680,8 +713,12 @@ __device__ __forceinline__ void glds_kc_pass_u(const float *wbase, int64_t step,
   if (!PRED || (int)(threadIdx.x & 15) + rb * 16 < rows_left) __builtin_amdgcn_global_load_lds((md_gbl_void *)(ub + lane_off), (md_lds_void *)(S + (rb * KH + kh) * 256), 16, 0, 0);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool B_KC, int EPI = 0, int RAGGED = 0>
+// NBUF = 3 (whole tiles, no epilogue; MDHIP_GEMM_NBUF=3, experiment): THREE LDS buffers per operand, the DMA runs TWO k-tiles ahead and the
+// k-tile boundary waits with a COUNTED `s_waitcnt vmcnt(PA + PB)` — the tile needed next is complete, the one just issued may still be
+// in flight — instead of the full drain a `__syncthreads()` brings (SQ counters: the small tiles park 20 % of their cycles there).
+template <int BM, int BN, int BK, int WM, int WN, bool B_KC, int EPI = 0, int RAGGED = 0, int NBUF = 2>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
+  static_assert(NBUF == 2 || (NBUF == 3 && EPI == 0 && RAGGED == 0), "three buffers: plain whole-tile kernel only");
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);
   constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NP = BK / 8, KH = BK / 16;
@@ -695,6 +732,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float A1[BM * BK];
   __shared__ __attribute__((aligned(16))) float B0[BN * BK];
   __shared__ __attribute__((aligned(16))) float B1[BN * BK];
+  __shared__ __attribute__((aligned(16))) float A2[NBUF == 3 ? BM * BK : 4];
+  __shared__ __attribute__((aligned(16))) float B2[NBUF == 3 ? BN * BK : 4];
 
   const int nblk = g.tiles_m * g.tiles_n;
   int bid = blockIdx.x;
@@ -741,6 +780,15 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
     if constexpr (B_KC) glds_kc_pass<BN, BK, NT, RAGGED != 0>(B, g.b_ns, n0, 0, B0, i, g.N, g.K, g.zero);
     else glds_tile_pass<BN, BK, NT, RAGGED != 0>(B, g.b_ks, n0, 0, B0, i, g.N, g.K, g.zero);
   }
+  if constexpr (NBUF == 3) {   // tile 1 into buffer 1 (K >= 2 k-tiles: the launcher checks)
+#pragma unroll
+    for (int i = 0; i < PA; ++i) glds_kc_pass<BM, BK, NT, false>(A, g.a_ms, m0, BK, A1, i, g.M, g.K, g.zero);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      if constexpr (B_KC) glds_kc_pass<BN, BK, NT, false>(B, g.b_ns, n0, BK, B1, i, g.N, g.K, g.zero);
+      else glds_tile_pass<BN, BK, NT, false>(B, g.b_ks, n0, BK, B1, i, g.N, g.K, g.zero);
+    }
+  }
   const uint32_t la = glds_kc_lane_off(g.a_ms), lb = B_KC ? glds_kc_lane_off(g.b_ns) : glds_tile_lane_off<BN>(g.b_ks);   // (loop-invariant lane parts of the DMA addresses)
   const int uw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float *wa = A + (m0 + (int64_t)uw * 16) * g.a_ms;   // uniform parts: adds only inside the loop
@@ -754,7 +802,13 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
     rlb = (int)(g.N - n0 < (1 << 30) ? g.N - n0 : (1 << 30));
     if constexpr (!B_KC) prb = n0 + (int64_t)((threadIdx.x & 63) % (BN / 4 > 64 ? 64 : BN / 4)) * 4 < g.N;
   }
-  __syncthreads();
+  if constexpr (NBUF == 3) {
+    constexpr int NW8 = PA + PB;
+    __builtin_amdgcn_s_waitcnt((NW8 & 0xF) | ((NW8 >> 4) << 14) | (7 << 4) | (15 << 8));   // tile 0 landed; tile 1 may still fly
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __syncthreads();
+  }
 
   f32x4 fa[2][WTM], fb[2][WTN];
   // fragments of k-pair j out of buffer BUF (compile-time) into register set c
@@ -762,11 +816,11 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
   {                                                                                                                             \
     const int joff = ((j) >> 1) * 256 + (((2 * (j)) & 3) * 64);   /* (a constant once the pair loop is unrolled) */             \
     _Pragma("unroll") for (int i = 0; i < WTM; ++i)                                                                             \
-      fa[c][i] = *reinterpret_cast<const f32x4 *>(((BUF) ? A1 : A0) + abase + i * (2 * KH * 256) + joff);                       \
+      fa[c][i] = *reinterpret_cast<const f32x4 *>(((BUF) == 0 ? A0 : (BUF) == 1 ? A1 : A2) + abase + i * (2 * KH * 256) + joff);                       \
     _Pragma("unroll") for (int q = 0; q < WTN; ++q) {                                                                           \
-      if constexpr (B_KC) fb[c][q] = *reinterpret_cast<const f32x4 *>(((BUF) ? B1 : B0) + bbase + q * (2 * KH * 256) + joff);   \
+      if constexpr (B_KC) fb[c][q] = *reinterpret_cast<const f32x4 *>(((BUF) == 0 ? B0 : (BUF) == 1 ? B1 : B2) + bbase + q * (2 * KH * 256) + joff);   \
       else {                                                                                                                    \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) fb[c][q][t] = ((BUF) ? B1 : B0)[bbase + (8 * (j) + t) * BN + q * 32];     \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) fb[c][q][t] = ((BUF) == 0 ? B0 : (BUF) == 1 ? B1 : B2)[bbase + (8 * (j) + t) * BN + q * 32];     \
       }                                                                                                                         \
     }                                                                                                                           \
   }
@@ -786,20 +840,20 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
         for (int q = 0; q < PPS; ++q) {
           const int pi = sidx * PPS + q;
           if (pi < PA) {
-            if constexpr (RAGGED == 1) glds_kc_pass<BM, BK, NT, true>(A, g.a_ms, m0, kn * BK, CUR ? A0 : A1, pi, g.M, g.K, g.zero);
-            else if constexpr (RAGGED == 2) glds_kc_pass_u<BM, BK, NT, true>(wa, sa, kn * BK, CUR ? A0 : A1, pi, la, rla);
-            else glds_kc_pass_u<BM, BK, NT>(wa, sa, kn * BK, CUR ? A0 : A1, pi, la);
+            if constexpr (RAGGED == 1) glds_kc_pass<BM, BK, NT, true>(A, g.a_ms, m0, kn * BK, (NBUF == 2 ? (CUR ? A0 : A1) : (CUR == 0 ? A2 : CUR == 1 ? A0 : A1)), pi, g.M, g.K, g.zero);
+            else if constexpr (RAGGED == 2) glds_kc_pass_u<BM, BK, NT, true>(wa, sa, kn * BK, (NBUF == 2 ? (CUR ? A0 : A1) : (CUR == 0 ? A2 : CUR == 1 ? A0 : A1)), pi, la, rla);
+            else glds_kc_pass_u<BM, BK, NT>(wa, sa, kn * BK, (NBUF == 2 ? (CUR ? A0 : A1) : (CUR == 0 ? A2 : CUR == 1 ? A0 : A1)), pi, la);
             ++n_dma;
           } else if (pi < PA + PB) {
             if constexpr (RAGGED == 1) {
-              if constexpr (B_KC) glds_kc_pass<BN, BK, NT, true>(B, g.b_ns, n0, kn * BK, CUR ? B0 : B1, pi - PA, g.N, g.K, g.zero);
-              else glds_tile_pass<BN, BK, NT, true>(B, g.b_ks, n0, kn * BK, CUR ? B0 : B1, pi - PA, g.N, g.K, g.zero);
+              if constexpr (B_KC) glds_kc_pass<BN, BK, NT, true>(B, g.b_ns, n0, kn * BK, (NBUF == 2 ? (CUR ? B0 : B1) : (CUR == 0 ? B2 : CUR == 1 ? B0 : B1)), pi - PA, g.N, g.K, g.zero);
+              else glds_tile_pass<BN, BK, NT, true>(B, g.b_ks, n0, kn * BK, (NBUF == 2 ? (CUR ? B0 : B1) : (CUR == 0 ? B2 : CUR == 1 ? B0 : B1)), pi - PA, g.N, g.K, g.zero);
             } else if constexpr (RAGGED == 2) {
-              if constexpr (B_KC) glds_kc_pass_u<BN, BK, NT, true>(wb, sb, kn * BK, CUR ? B0 : B1, pi - PA, lb, rlb);
-              else glds_tile_pass_u<BN, BK, NT, true>(wb, sb, kn * BK * g.b_ks, CUR ? B0 : B1, pi - PA, lb, prb);
+              if constexpr (B_KC) glds_kc_pass_u<BN, BK, NT, true>(wb, sb, kn * BK, (NBUF == 2 ? (CUR ? B0 : B1) : (CUR == 0 ? B2 : CUR == 1 ? B0 : B1)), pi - PA, lb, rlb);
+              else glds_tile_pass_u<BN, BK, NT, true>(wb, sb, kn * BK * g.b_ks, (NBUF == 2 ? (CUR ? B0 : B1) : (CUR == 0 ? B2 : CUR == 1 ? B0 : B1)), pi - PA, lb, prb);
             } else {
-              if constexpr (B_KC) glds_kc_pass_u<BN, BK, NT>(wb, sb, kn * BK, CUR ? B0 : B1, pi - PA, lb);
-              else glds_tile_pass_u<BN, BK, NT>(wb, sb, kn * BK * g.b_ks, CUR ? B0 : B1, pi - PA, lb);
+              if constexpr (B_KC) glds_kc_pass_u<BN, BK, NT>(wb, sb, kn * BK, (NBUF == 2 ? (CUR ? B0 : B1) : (CUR == 0 ? B2 : CUR == 1 ? B0 : B1)), pi - PA, lb);
+              else glds_tile_pass_u<BN, BK, NT>(wb, sb, kn * BK * g.b_ks, (NBUF == 2 ? (CUR ? B0 : B1) : (CUR == 0 ? B2 : CUR == 1 ? B0 : B1)), pi - PA, lb);
             }
             ++n_dma;
           }
@@ -823,15 +877,35 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
         }
       }
     }
-    __syncthreads();
-    MD_KC_READ(CUR ^ 1, 0, 0)
+    if constexpr (NBUF == 2) {
+      __syncthreads();
+      MD_KC_READ(CUR ^ 1, 0, 0)
+    } else {
+      // counted wait: this wave's DMAs of the tile computed NEXT are done (issued a whole k-tile ago), the PA + PB it issued in this
+      // tile may still fly; the barrier then publishes every wave's share of the next tile and frees this tile's buffer
+      constexpr int NW8 = PA + PB;
+      __builtin_amdgcn_s_waitcnt((NW8 & 0xF) | ((NW8 >> 4) << 14) | (7 << 4) | (15 << 8));
+      __builtin_amdgcn_s_barrier();
+      MD_KC_READ((CUR + 1) % 3, 0, 0)
+    }
   };
   int64_t kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    ktile(MdInt<0>{}, kt + 1);
-    ktile(MdInt<1>{}, kt + 2 < nk ? kt + 2 : nk - 1);
+  if constexpr (NBUF == 2) {
+    for (; kt + 1 < nk; kt += 2) {
+      ktile(MdInt<0>{}, kt + 1);
+      ktile(MdInt<1>{}, kt + 2 < nk ? kt + 2 : nk - 1);
+    }
+    if (kt < nk) ktile(MdInt<0>{}, nk - 1);
+  } else {
+    // tile T is computed out of buffer T % 3 while the DMAs of tile T + 2 go out (past the end: a discarded re-read of the last tile)
+    for (; kt + 2 < nk; kt += 3) {
+      ktile(MdInt<0>{}, kt + 2);
+      ktile(MdInt<1>{}, kt + 3 < nk ? kt + 3 : nk - 1);
+      ktile(MdInt<2>{}, kt + 4 < nk ? kt + 4 : nk - 1);
+    }
+    if (kt < nk) ktile(MdInt<0>{}, nk - 1);
+    if (kt + 1 < nk) ktile(MdInt<1>{}, nk - 1);
   }
-  if (kt < nk) ktile(MdInt<0>{}, nk - 1);
 #undef MD_KC_READ
 
   if (g.stamp && threadIdx.x == 0) {
@@ -904,6 +978,18 @@ static const float *md_zero_block() {
     return (const float *)p;
   }();
   return z;
+}
+
+// Three LDS buffers (DMA two k-tiles ahead, counted vmcnt at the k-tile boundary) for the 128-row direct-to-LDS tiles: when the grid
+// gives a CU one block at most — the third buffer's 32 KiB cost nothing then, and such grids (2048^3, the 1024-row shards of an 8-rank
+// cfg4, the all-reduce panels) are the ones whose k-tile (1.7 us) is about one DMA round trip: 2048^3 NN 132.9 -> 139.0, NT 132.7 ->
+// 140.1 TFLOP/s (profiles/r3_gemm_nbuf_ab.log). Larger grids keep two buffers and two blocks per CU. MDHIP_GEMM_NBUF=2 / 3 forces
+// (read at every launch: A/B runs, exactness tests).
+static bool md_gemm_nbuf3(int64_t blocks, int64_t K, int bk) {
+  if (K < 2 * bk) return false;
+  const char *e = getenv("MDHIP_GEMM_NBUF");
+  if (e) return atoi(e) == 3;
+  return blocks <= MD_NUM_CUS;
 }
 
 // Launch of a main GEMM kernel: with events attached (mdhip_event_attach_next, bench.py) the dispatch itself carries the start / stop
@@ -1020,7 +1106,15 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
         // (135.7 -> 130.8: its k-tile is too short for a one-tile-ahead DMA) and keeps its registers.
         const char *e = getenv("MDHIP_GEMM_GLDS");
         glds = (e ? atoi(e) != 0 : true) && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp && ga.a_ks > 0 && ga.b_ks > 0 && ga.a_ks < (1ll << 26) && ga.b_ks < (1ll << 26);   // (32-bit lane offsets)
-        if (glds) md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN>, grid, 64 * WM * WN, ga);
+        if (glds) {
+          if constexpr (3 * (BM + BN) * BK * 4 <= 128 * 1024) {
+            if (md_gemm_nbuf3((int64_t)grid.x * grid.z, ga.K, BK)) {
+              md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN, 0, 3>, grid, 64 * WM * WN, ga);
+              return MD_LAUNCH_CHECK("matmul(f32 mfma, direct-to-LDS TN, 3 buffers)");
+            }
+          }
+          md_gemm_launch(k_gemm_f32_tn_glds<BM, BN, BK, WM, WN>, grid, 64 * WM * WN, ga);
+        }
       }
       if (!glds) md_gemm_launch(k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, false, false, SCHED>, grid, 64 * WM * WN, ga);
     }
@@ -1102,6 +1196,12 @@ static int launch_kc_glds(GemmArgs ga, int64_t batch, bool edge) {
       if (ga.K % BK == 0 && BM <= 128) md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, 0, 2>, grid, 64 * WM * WN, ga);   // (as in launch_cfg's TN branch)
       else md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, 0, 1>, grid, 64 * WM * WN, ga);
       return MD_LAUNCH_CHECK("matmul(f32 mfma, direct-to-LDS, ragged)");
+    }
+  }
+  if constexpr (EPI == 0 && BM <= 128) {
+    if (md_gemm_nbuf3((int64_t)grid.x * grid.z, ga.K, BK)) {
+      md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, 0, 0, 3>, grid, 64 * WM * WN, ga);
+      return MD_LAUNCH_CHECK("matmul(f32 mfma, direct-to-LDS, 3 buffers)");
     }
   }
   md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, EPI>, grid, 64 * WM * WN, ga);

@@ -14,8 +14,13 @@ from minidiff_amd import _capi, ndarray as nd  # noqa: E402
 CFGS = {-1: "auto (tile picker)", 0: "128x128x16", 1: "64x64x16", 2: "128x64x16", 3: "256x128x16", 4: "256x256x32 (TN)", 5: "128x128x32 (TN)", 6: "128x64x32 (TN)", 7: "128x128 8 waves"}
 if os.environ.get("GEMM_CFGS"):
     CFGS = {int(k): CFGS[int(k)] for k in os.environ["GEMM_CFGS"].split(",")}
+if os.environ.get("GEMM_NBUF_AB"):   # every config twice: two / three LDS buffers in the k-contiguous direct-to-LDS kernel (MDHIP_GEMM_NBUF, read per launch)
+    CFGS = {(99 if k == -1 else k) + 1000 * g: v + (" +3buf" if g else "") for k, v in CFGS.items() for g in (0, 1)}
 if os.environ.get("GEMM_GLDS_AB"):   # every config twice: register staging / direct-to-LDS staging (MDHIP_GEMM_GLDS is read per launch)
     CFGS = {(99 if k == -1 else k) + 100 * g: v + (" +glds" if g else "") for k, v in CFGS.items() for g in (0, 1)}   # (99 = auto)
+
+
+REPS = int(os.environ.get("GEMM_REPS", "5"))   # launches per timing (small shapes: more, the gaps between 5 short launches weigh)
 
 
 def main():
@@ -39,6 +44,8 @@ def main():
             nd.matmul(A, B)         # spread of round 2's log was the first round of each shape, taken cold)
         for rnd in range(rounds):
             for cfg in CFGS:
+                if os.environ.get("GEMM_NBUF_AB"):
+                    os.environ["MDHIP_GEMM_NBUF"] = "3" if cfg >= 1000 else "2"
                 if cfg % 100 == 99 or cfg == -1:
                     os.environ.pop("MDHIP_GEMM_CFG", None)      # the library's own choice
                 else:
@@ -50,11 +57,11 @@ def main():
                     nd.matmul(a, b)  # warm
                     nd.matmul(a, b)
                     lib.event_record(e0)
-                    for _ in range(5):
+                    for _ in range(REPS):
                         out = nd.matmul(a, b)
                     lib.event_record(e1)
                     lib.event_elapsed_ms(e0, e1, C.byref(ms))
-                    tf = 5 * 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
+                    tf = REPS * 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
                     res.setdefault((cfg, tag), []).append(tf)
                     if rnd == 0:
                         h = out.get()
@@ -66,6 +73,7 @@ def main():
             print("   %-22s " % name + "  ".join("%s med %6.1f min %6.1f max %6.1f TF" % (t, sorted(res[(cfg, t)])[len(res[(cfg, t)]) // 2], min(res[(cfg, t)]), max(res[(cfg, t)])) for t in (("NN", "NT", "TN", "TT") if os.environ.get("GEMM_TT") else ("NN", "NT", "TN"))))
     os.environ.pop("MDHIP_GEMM_CFG", None)
     os.environ.pop("MDHIP_GEMM_GLDS", None)
+    os.environ.pop("MDHIP_GEMM_NBUF", None)
 
 
 if __name__ == "__main__":
