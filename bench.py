@@ -564,6 +564,11 @@ def main():
                 run_one = captured.replay
             except RuntimeError as e:
                 captured, segmented = None, False
+                try:        # the failed capture may have stopped inside backward(): put the gradient sync back to "between sweeps"
+                    sync()
+                except Exception:
+                    pass
+                lib.sync()
                 if rank == 0:
                     print(f"[bench] segmented graph capture unavailable ({e}); eager sweeps", file=sys.stderr)
                 run_one = sweep
