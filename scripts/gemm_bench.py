@@ -15,7 +15,7 @@ CFGS = {-1: "auto (tile picker)", 0: "128x128x16", 1: "64x64x16", 2: "128x64x16"
 if os.environ.get("GEMM_CFGS"):
     CFGS = {int(k): CFGS[int(k)] for k in os.environ["GEMM_CFGS"].split(",")}
 if os.environ.get("GEMM_NBUF_AB"):   # every config twice: two / three LDS buffers in the k-contiguous direct-to-LDS kernel (MDHIP_GEMM_NBUF, read per launch)
-    CFGS = {(99 if k == -1 else k) + 1000 * g: v + (" +3buf" if g else "") for k, v in CFGS.items() for g in (0, 1)}
+    CFGS = {(99 if k == -1 else k) + 1000 * g: v + (" %dbuf" % (g + 2)) for k, v in CFGS.items() for g in (0, 1)}
 if os.environ.get("GEMM_GLDS_AB"):   # every config twice: register staging / direct-to-LDS staging (MDHIP_GEMM_GLDS is read per launch)
     CFGS = {(99 if k == -1 else k) + 100 * g: v + (" +glds" if g else "") for k, v in CFGS.items() for g in (0, 1)}   # (99 = auto)
 
@@ -45,7 +45,7 @@ def main():
         for rnd in range(rounds):
             for cfg in CFGS:
                 if os.environ.get("GEMM_NBUF_AB"):
-                    os.environ["MDHIP_GEMM_NBUF"] = "3" if cfg >= 1000 else "2"
+                    os.environ["MDHIP_GEMM_NBUF"] = str(2 + cfg // 1000)
                 if cfg % 100 == 99 or cfg == -1:
                     os.environ.pop("MDHIP_GEMM_CFG", None)      # the library's own choice
                 else:
