@@ -152,8 +152,18 @@ def install(ns: dict):
         npf = getattr(np, _NP_NAME.get(name, name) or "zeros")
 
         def wrapped(*args, **kw):
-            if not any_narrow(args, kw):
-                return fn(*args, **kw)
+            for x in args:                         # the common case inline: device arrays of the compute dtypes and Python scalars
+                tx = type(x)
+                if tx is DeviceArray:
+                    if x._code >= NARROW_CODE_MIN:
+                        break
+                elif tx is int or tx is float or tx is bool or x is None:
+                    continue
+                elif has_narrow(x):
+                    break
+            else:
+                if not kw or not any_narrow((), kw):
+                    return fn(*args, **kw)
             if name == "getitem" and basic_key(args[1]):
                 return fn(*args, **kw)          # a view: strides only, no kernel
             # NumPy's own verdict on dtypes (and its exceptions) from one-element dummies

@@ -140,13 +140,21 @@ def _pinned_empty(shape, dtype, nbytes):
     return np.frombuffer(view, dtype=dtype).reshape(shape)
 
 
+_C_STRIDES: dict = {}
+_DESC_TEMPLATES: dict = {}
+
+
 def _c_strides(shape) -> tuple:
-    st = [0] * len(shape)
-    acc = 1
-    for i in range(len(shape) - 1, -1, -1):
-        st[i] = acc
-        acc *= shape[i]
-    return tuple(st)
+    st = _C_STRIDES.get(shape)           # (the same few shapes recur in every sweep: a dict hit instead of a loop per result array)
+    if st is None:
+        acc, out = 1, [0] * len(shape)
+        for i in range(len(shape) - 1, -1, -1):
+            out[i] = acc
+            acc *= shape[i]
+        st = tuple(out)
+        if len(_C_STRIDES) < 4096:
+            _C_STRIDES[shape] = st
+    return st
 
 
 def _prod(shape) -> int:
@@ -409,14 +417,21 @@ class DeviceArray:
         if shape is None or shape == self.shape:
             d = self._cdesc
             if d is None:
-                d = ArrayDesc()
+                key = (self.shape, self._strides, self._code)
+                tmpl = _DESC_TEMPLATES.get(key)      # geometry part of the descriptor: built once per (shape, strides, dtype), then copied
+                if tmpl is None:
+                    t = ArrayDesc()
+                    t.dtype = self._code
+                    nd = len(self.shape)
+                    t.ndim = nd
+                    if nd:
+                        t.shape[:nd] = self.shape
+                        t.strides[:nd] = self._strides
+                    tmpl = bytes(t)
+                    if len(_DESC_TEMPLATES) < 4096:
+                        _DESC_TEMPLATES[key] = tmpl
+                d = ArrayDesc.from_buffer_copy(tmpl)
                 d.data = self.ptr
-                d.dtype = self._code
-                nd = len(self.shape)
-                d.ndim = nd
-                if nd:
-                    d.shape[:nd] = self.shape
-                    d.strides[:nd] = self._strides
                 self._cdesc = d
             return d
         d = ArrayDesc()
