@@ -222,6 +222,20 @@ class Library:
 _LIB: Library | None = None
 
 
+_BIND_HOOKS: list = []   # callables(lib): told whenever the process is bound to a library (ndarray hands its entry points to _fastpath)
+
+
+def _bound(lib: "Library") -> "Library":
+    for hook in _BIND_HOOKS:
+        hook(lib)
+    return lib
+
+
+def entry_address(lib: "Library", name: str) -> int:
+    """Address of a C-ABI symbol of `lib` (for host code that calls it without ctypes: csrc/fastpath.c)."""
+    return C.cast(getattr(lib.cdll, name), C.c_void_p).value
+
+
 def load() -> Library:
     """Return the process-wide library, loading the PRODUCT build on first use."""
     global _LIB
@@ -241,7 +255,7 @@ def load() -> Library:
                 raise ImportError(f"{path} reports target {lib.target!r}, expected {PRODUCT_TARGET!r}")
             _LIB = lib
             _LIB.ensure_init()
-            return _LIB
+            return _bound(_LIB)
         if not os.path.exists(PRODUCT_LIB):
             raise ImportError(
                 f"{PRODUCT_LIB} is missing: the HIP extension has not been built. "
@@ -252,6 +266,8 @@ def load() -> Library:
         if lib.target != PRODUCT_TARGET:
             raise ImportError(f"{PRODUCT_LIB} reports target {lib.target!r}, expected {PRODUCT_TARGET!r}")
         _LIB = lib
+        _LIB.ensure_init()
+        return _bound(_LIB)
     _LIB.ensure_init()
     return _LIB
 
@@ -261,7 +277,7 @@ def use_library(path: str, device: int | None = None) -> Library:
     global _LIB
     _LIB = Library(path)
     _LIB.ensure_init(device)
-    return _LIB
+    return _bound(_LIB)
 
 
 def current() -> Library | None:

@@ -32,6 +32,19 @@ from . import lazy as _lz
 from . import narrow as _narrow
 from ._capi import ArrayDesc, IndexPlan, MAX_NDIM
 
+# The C route of eager calls (csrc/fastpath.c): block owner, array fields and the float elementwise entries in C. Off with
+# MDHIP_FASTPATH=0 (A/B of the host cost, scripts/host_overhead.py) and under MDHIP_TRACE (the call log sits in the ctypes layer).
+if os.environ.get("MDHIP_FASTPATH", "1") != "0" and not os.environ.get("MDHIP_TRACE"):
+    try:
+        from . import _fastpath as _fp
+    except ImportError as e:  # built by `make -C minidiff_amd/csrc` next to libmdhip.so
+        raise ImportError(f"minidiff_amd/_fastpath extension is missing ({e}): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or set MDHIP_FASTPATH=0 for the pure-Python host path") from e
+    if _fp.ABI_DESC_BYTES != C.sizeof(ArrayDesc):
+        raise ImportError("minidiff_amd/_fastpath was built against another include/mdhip.h: rebuild (make -C minidiff_amd/csrc)")
+else:
+    _fp = None
+
 # Lazy fusion of elementwise chains (minidiff_amd/lazy.py) is opt-in; eager —
 # one kernel per backend call, the reference's execution model — is the default.
 _LAZY = os.environ.get("MDHIP_LAZY", "0") == "1"
@@ -41,6 +54,8 @@ def set_lazy(flag: bool) -> bool:
     """Switch lazy fusion on/off; returns the previous setting."""
     global _LAZY
     prev, _LAZY = _LAZY, py_bool(flag)
+    if _fp is not None:
+        _fp.set_lazy(_LAZY)
     return prev
 
 
@@ -86,8 +101,9 @@ def _lib() -> _capi.Library:
     return lib
 
 
-class _Buffer:
-    """Owner of one allocator block; freed when the last view drops it."""
+class _PyBuffer:
+    """Owner of one allocator block; freed when the last view drops it. (Pure-Python form; `_fastpath.Buffer` is the same
+    object in C and the one in use unless MDHIP_FASTPATH=0 / MDHIP_TRACE.)"""
 
     __slots__ = ("ptr", "nbytes", "_free", "deps", "task", "__weakref__")
 
@@ -109,6 +125,8 @@ class _Buffer:
         except Exception:  # interpreter teardown
             pass
 
+
+_Buffer = _fp.Buffer if _fp is not None else _PyBuffer
 
 _PINNED_MIN = 1 << 20
 
@@ -192,22 +210,28 @@ def normalize_axes(axis, ndim) -> tuple:
     return (normalize_axis(axis, ndim),)
 
 
-class DeviceArray:
-    __slots__ = ("_buf", "_offset", "shape", "_strides", "dtype", "_code", "_expr", "_cdesc", "_tasks", "_dependents", "__weakref__")
+class DeviceArray(_fp.ArrayBase if _fp is not None else object):
+    # fields (a C struct in _fastpath.ArrayBase, slots otherwise): _buf, _offset, shape, _strides, dtype, _code,
+    #   _expr        pending expression (lazy mode); _buf is None until materialised
+    #   _cdesc       own-shape C descriptor, built once (geometry and block never change)
+    #   _tasks       weakrefs to deferred reductions of this pending expression (_ColsTask)
+    #   _dependents  pending arrays that took THIS pending product as a leaf before it had a block
+    __slots__ = () if _fp is not None else ("_buf", "_offset", "shape", "_strides", "dtype", "_code", "_expr", "_cdesc", "_tasks", "_dependents", "__weakref__")
     __array_priority__ = 1000.0
     __hash__ = None
 
-    def __init__(self, buf: _Buffer, offset: int, shape: tuple, strides: tuple, dtype: np.dtype, code: int = -1):
-        self._buf = buf
-        self._offset = offset
-        self.shape = shape
-        self._strides = strides
-        self.dtype = dtype
-        self._code = code if code >= 0 else dtype_code(dtype)
-        self._expr = None  # pending expression (lazy mode); _buf is None until materialised
-        self._cdesc = None  # own-shape C descriptor, built once (geometry and block never change)
-        self._tasks = None  # weakrefs to deferred reductions of this pending expression (_ColsTask)
-        self._dependents = None  # pending arrays that took THIS pending product as a leaf before it had a block
+    if _fp is None:
+        def __init__(self, buf: _Buffer, offset: int, shape: tuple, strides: tuple, dtype: np.dtype, code: int = -1):
+            self._buf = buf
+            self._offset = offset
+            self.shape = shape
+            self._strides = strides
+            self.dtype = dtype
+            self._code = code if code >= 0 else dtype_code(dtype)
+            self._expr = None
+            self._cdesc = None
+            self._tasks = None
+            self._dependents = None
 
     # ---- lazy evaluation -----------------------------------------------------
     @staticmethod
@@ -329,6 +353,8 @@ class DeviceArray:
     def _new(shape: tuple, dtype: np.dtype) -> "DeviceArray":
         """Result buffer of an op: `shape` is already a validated tuple of ints, `dtype` an np.dtype
         (skips the argument normalisation of `empty`; the dispatch cost of a small op is Python)."""
+        if _fp is not None:
+            return _fp.new_array(shape, dtype, dtype_code(dtype))
         n = dtype.itemsize
         for s in shape:
             n *= s
@@ -2570,3 +2596,39 @@ def random_permutation(n: int):
 # storage-only dtypes (float16, int8/16, uint8/16/32/64): the computing functions above are wrapped so that a call with such an
 # operand runs promote -> wide kernel -> demote; calls on the compute dtypes pay one flag test per argument (narrow.py)
 _narrow.install(globals())
+
+
+# ---- the C route in front of the float elementwise entries (csrc/fastpath.c) -------------------------------------------------
+def _install_fastpath(ns):
+    if _fp is None:
+        return
+
+    def raise_status(st):
+        lib = _lib()
+        raise _capi._EXC.get(st, RuntimeError)(lib.cdll.mdhip_last_error().decode(errors="replace"))
+
+    by_code = {c: dt for dt, c in _DTYPE_CODES.items() if c < _NARROW_MIN}
+    _fp.configure(DeviceArray, tuple(by_code[c] for c in range(_NARROW_MIN)), dtype_code, raise_status, _lib)
+    _fp.set_lazy(_LAZY)
+
+    def bind(lib):
+        _fp.bind({name: _capi.entry_address(lib, name) for name in ("mdhip_alloc", "mdhip_free", "mdhip_unary", "mdhip_binary", "mdhip_reduce")})
+        _fp.enable_ops(True)
+
+    _capi._BIND_HOOKS.append(bind)
+    if _capi._LIB is not None:
+        bind(_capi._LIB)
+    unary = {"absolute": _capi.U_ABS, "negative": _capi.U_NEG, "sign": _capi.U_SIGN, "ceil": _capi.U_CEIL, "floor": _capi.U_FLOOR,
+             "sin": _capi.U_SIN, "cos": _capi.U_COS, "tan": _capi.U_TAN, "sinh": _capi.U_SINH, "cosh": _capi.U_COSH, "tanh": _capi.U_TANH,
+             "exp": _capi.U_EXP, "log": _capi.U_LOG, "sqrt": _capi.U_SQRT, "logical_not": _capi.U_LOGICAL_NOT, "isnan": _capi.U_ISNAN}
+    binary = {"add": _capi.B_ADD, "subtract": _capi.B_SUB, "multiply": _capi.B_MUL, "true_divide": _capi.B_TRUE_DIV,
+              "floor_divide": _capi.B_FLOOR_DIV, "mod": _capi.B_MOD, "power": _capi.B_POW, "maximum": _capi.B_MAXIMUM,
+              "minimum": _capi.B_MINIMUM, "equal": _capi.B_EQ, "not_equal": _capi.B_NE, "less": _capi.B_LT, "less_equal": _capi.B_LE,
+              "greater": _capi.B_GT, "greater_equal": _capi.B_GE}
+    for name, code in unary.items():
+        ns[name] = _fp.FastOp(1, code, ns[name], name)
+    for name, code in binary.items():
+        ns[name] = _fp.FastOp(2, code, ns[name], name)
+
+
+_install_fastpath(globals())

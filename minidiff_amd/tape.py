@@ -195,9 +195,12 @@ def build_engine(B, name: str = "engine"):
             self.kwargs = kwargs or {}
             self.name = name or ""
             self.pass_kwargs = pass_kwargs
-            self.tensor_inputs = [x for x in inputs if isinstance(x, Tensor)]
-            for t in self.tensor_inputs:
-                t.graph_refs += 1
+            tin = []
+            for x in inputs:
+                if isinstance(x, Tensor):
+                    tin.append(x)
+                    x.graph_refs += 1
+            self.tensor_inputs = tin
             self.op_ids = None
             if caching_on.get():  # structural id (topology.py:52-63)
                 # (a producer enters by its HASH, not by its nested id tuple: tuple hashes are not cached, and hashing nested
@@ -223,14 +226,15 @@ def build_engine(B, name: str = "engine"):
             expects: hooked inputs are served first and their hook fires the moment the
             last contribution has been accumulated, so a collective on that gradient
             overlaps the vjps that remain."""
-            order = range(len(self.inputs))
+            inputs, vjps = self.inputs, self.vjps
+            order = range(len(inputs))
             if pending:
-                order = sorted(order, key=lambda i: id(self.inputs[i]) not in pending)  # stable: hooked first
+                order = sorted(order, key=lambda i: id(inputs[i]) not in pending)  # stable: hooked first
+            kw = self.kwargs if self.pass_kwargs else None
             for i in order:
-                inp, vjp = self.inputs[i], self.vjps[i]
-                if vjp is None or not isinstance(inp, Tensor) or not inp.allow_grad:
+                inp, vjp = inputs[i], vjps[i]
+                if vjp is None or not isinstance(inp, Tensor) or not inp._allow_grad:
                     continue
-                kw = self.kwargs if self.pass_kwargs else {}
                 g = None
                 if pending and pending.get(id(inp)) == 1 and inp.grad is None and not E.grad_allowed_():
                     # the ONLY contribution to a hooked leaf, first order: its hook may produce the gradient itself
@@ -239,7 +243,7 @@ def build_engine(B, name: str = "engine"):
                     if producer is not None:
                         g = producer(self, i, grad)
                 if g is None:
-                    g = vjp(*self.inputs, grad, **kw)
+                    g = vjp(*inputs, grad, **kw) if kw else vjp(*inputs, grad)
                 if g.shape != inp.shape:
                     g = E.unbroadcast(g, inp.shape)
                 inp.grad = g if inp.grad is None else inp.grad + g
@@ -368,7 +372,7 @@ def build_engine(B, name: str = "engine"):
             self._allow_grad = allow
 
         T = property(lambda self: E.transpose(self))
-        shape = property(lambda self: B.tensor_shape(self._data))
+        shape = property(lambda self, _f=B.tensor_shape: _f(self._data))
         size = property(lambda self: B.tensor_size(self._data))
         ndim = property(lambda self: B.tensor_ndim(self._data))
         dtype = property(lambda self: B.tensor_dtype(self._data))
@@ -485,6 +489,19 @@ def build_engine(B, name: str = "engine"):
             return B.array(self._data, dtype=dtype, copy=copy)
 
     E.Tensor = Tensor
+    _tensor_class = B.tensor_class
+
+    def _wrap(data, allow):
+        """Tensor(data, allow_grad=allow) for a value that IS a backend array (an op's result): the fields, without the
+        constructor's unwrapping and conversion."""
+        t = Tensor.__new__(Tensor)
+        t._data = data
+        t._allow_grad = allow
+        t._iterator = None
+        t.graph_refs = 0
+        t.grad = None
+        t.op_node = None
+        return t
 
     # ------------------------------------------------------- op construction ----
     def _wants_grad(inputs):
@@ -515,8 +532,9 @@ def build_engine(B, name: str = "engine"):
             # (the common call — Tensors and scalars, no keyword arguments — without the generic recursion)
             raw = [a._data if type(a) is Tensor else (a if type(a) in _PLAIN else try_unwrap(a)) for a in args]
             out = fn(*raw, **try_unwrap(kwargs)) if kwargs else fn(*raw)
-            return Tensor(out, allow_grad=allow)
+            return _wrap(out, allow) if type(out) is _tensor_class else Tensor(out, allow_grad=allow)
         lifted.__name__ = getattr(fn, "__name__", "backend_fn")
+        lifted.backend_fn = fn
         return lifted
 
     E.as_minidiff = lift
@@ -525,6 +543,34 @@ def build_engine(B, name: str = "engine"):
         if not differentiable:
             vjps = [None] * len(vjps)
         opname = name or forward.__name__
+        raw_fn = getattr(forward, "backend_fn", None)
+
+        def lifted_op(*inputs, **kwargs):
+            """`op` below for a forward that is a lifted backend function: input check, gradient mode, unwrapping and
+            wrapping in one pass over the arguments (same checks, same errors, same backend call)."""
+            allow, n_t, raw = False, 0, []
+            for a in inputs:
+                if type(a) is Tensor or isinstance(a, Tensor):
+                    n_t += 1
+                    if a._allow_grad:
+                        allow = True
+                    raw.append(a._data)
+                elif type(a) in _PLAIN:
+                    raw.append(a)
+                else:
+                    raw.append(try_unwrap(a))
+            if tensor_only:
+                if n_t != len(inputs) or n_t == 0:
+                    raise ValueError("This function only supports minidiff Tensors")
+            elif n_t == 0:
+                raise ValueError("This function requires at least one minidiff Tensor argument")
+            if allow and not grad_on.get():
+                allow = False
+            data = raw_fn(*raw, **try_unwrap(kwargs)) if kwargs else raw_fn(*raw)
+            out = _wrap(data, allow) if type(data) is _tensor_class else Tensor(data, allow_grad=allow)
+            if differentiable and allow:
+                out.op_node = Node(vjps, inputs, kwargs, opname, pass_kwargs)
+            return out
 
         def op(*inputs, **kwargs):
             _check_inputs(inputs, tensor_only)
@@ -537,6 +583,8 @@ def build_engine(B, name: str = "engine"):
                 out.op_node = Node(vjps, inputs, kwargs, opname, pass_kwargs)
             return out
 
+        if raw_fn is not None:
+            op = lifted_op
         op.__name__ = opname
         op.__qualname__ = f"<op func '{opname}'>"
         return op

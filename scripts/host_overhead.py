@@ -6,6 +6,33 @@ from minidiff_amd import _capi, ndarray as nd, workloads
 from minidiff_amd.tape import hip_engine
 lib = _capi.load()
 md = hip_engine()
+if sys.argv[1] == "calls":
+    # host cost of single eager backend calls (8 elements: the device side is nothing), C route (csrc/fastpath.c) vs the Python
+    # implementation behind it; run again with MDHIP_FASTPATH=0 for the all-Python path of round 2 (Python block owner too)
+    import numpy as np
+    a = nd.asarray(np.ones(8, dtype=np.float32)); b = nd.asarray(np.ones(8, dtype=np.float32))
+
+    def t(f, n=20000):
+        for _ in range(2000):
+            f()
+        lib.sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            f()
+        dt = (time.perf_counter() - t0) / n * 1e6
+        lib.sync()
+        return dt
+    print("fast path:", "on" if nd._fp is not None else "off (MDHIP_FASTPATH=0)")
+    r = nd.DeviceArray._new((8,), a.dtype)
+    da, db, dr = a.desc(), b.desc(), r.desc()
+    print("lib.binary (ctypes, descriptors ready)  %6.2f us   <- C-ABI call + launch" % t(lambda: lib.binary(_capi.B_ADD, da, db, dr, _capi.F32)))
+    for name, f in (("add(a, b)", lambda: nd.add(a, b)), ("multiply(a, 2.0)", lambda: nd.multiply(a, 2.0)), ("sin(a)", lambda: nd.sin(a)),
+                    ("a + b (dunder)", lambda: a + b), ("sum(a)", lambda: nd.sum(a)), ("DeviceArray._new", lambda: nd.DeviceArray._new((8,), a.dtype))):
+        print("%-40s%6.2f us" % (name, t(f)))
+    if nd._fp is not None:
+        for name, f in (("add(a, b)  [Python implementation]", lambda: nd.add.__wrapped__(a, b)), ("sin(a)  [Python implementation]", lambda: nd.sin.__wrapped__(a))):
+            print("%-40s%6.2f us" % (name, t(f)))
+    sys.exit(0)
 wl, lazy = sys.argv[1], len(sys.argv) > 2 and sys.argv[2] == "lazy"
 nd.set_lazy(lazy)
 state, step = workloads.MAKERS[wl](md)
