@@ -22,6 +22,7 @@
 #include <structmember.h>
 #include <stdint.h>
 #include <string.h>
+#include <time.h>
 
 #include "mdhip.h"
 
@@ -774,7 +775,37 @@ static PyObject *fp_stats(PyObject *mod, PyObject *unused) {
   return Py_BuildValue("{s:K,s:K,s:i,s:i}", "served", G.served, "passed", G.passed, "enabled", G.ops_enabled, "lazy", G.lazy);
 }
 
+/* time_binary(op, a, b, n) -> seconds for n calls of mdhip_binary on prepared descriptors (one result block, reused): the
+ * C-ABI call + launch alone, i.e. the floor under any host route (scripts/host_overhead.py calls). */
+static PyObject *fp_time_binary(PyObject *mod, PyObject *args) {
+  int op;
+  PyObject *pa, *pb;
+  Py_ssize_t n;
+  if (!PyArg_ParseTuple(args, "iOOn", &op, &pa, &pb, &n)) return NULL;
+  if (ensure_bound() < 0) return NULL;
+  Operand a, b;
+  if (!G.array_type || !parse_operand(pa, &a) || !parse_operand(pb, &b) || !a.is_array || !b.is_array || a.code != b.code || a.ndim != b.ndim ||
+      memcmp(a.shape, b.shape, sizeof(int64_t) * a.ndim) || binary_out_code(op, a.code) < 0) {
+    PyErr_SetString(PyExc_ValueError, "time_binary: two float arrays of one dtype and shape");
+    return NULL;
+  }
+  mdhip_array da, db, dr;
+  operand_desc(&a, a.ndim, a.shape, &da);
+  operand_desc(&b, a.ndim, a.shape, &db);
+  ArrayObject *r = result_array(a.ndim, a.shape, binary_out_code(op, a.code), &a, &b, &dr);
+  if (!r) return PyErr_Occurred() ? NULL : PyErr_NoMemory();
+  struct timespec t0, t1;
+  int st = 0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (Py_ssize_t i = 0; i < n && !st; i++) st = G.binary(op, &da, &db, &dr, a.code);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  Py_DECREF(r);
+  if (st) return raise_status(st);
+  return PyFloat_FromDouble((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+}
+
 static PyMethodDef module_methods[] = {
+    {"time_binary", fp_time_binary, METH_VARARGS, "time_binary(op, a, b, n) -> seconds for n C-ABI calls on prepared descriptors"},
     {"new_array", (PyCFunction)(void (*)(void))fp_new_array, METH_FASTCALL, "new_array(shape, dtype, code) -> DeviceArray over a fresh block"},
     {"bind", fp_bind, METH_O, "bind({symbol: address}) — C-ABI entry points of the bound library"},
     {"configure", fp_configure, METH_VARARGS, "configure(array_type, dtypes, dtype_code, raise_status, loader)"},
