@@ -78,6 +78,9 @@ struct GemmArgs {
   // elements (repacked copy, HipExec::gemm): a 16-B piece that straddles the M (N) edge reads the padding, which only feeds
   // output rows (columns) outside C — so M (N) need not be a multiple of 4 for the direct-to-LDS kernels
   int pad_m, pad_n;
+  // C is addressed with unit stride along ROWS (a swapped "TT" product, HipExec::gemm) and everything is 16-B aligned: the direct-to-LDS
+  // NN kernel stores the four consecutive rows a lane holds of one column as one vector
+  int c_vec_rows;
 };
 
 // Tile loaders for a ROWS x BK operand tile, NT threads, 16 B per thread per pass.
@@ -716,9 +719,12 @@ __device__ __forceinline__ void glds_kc_pass_u(const float *wbase, int64_t step,
 // NBUF = 3 (whole tiles, no epilogue; MDHIP_GEMM_NBUF=3, experiment): THREE LDS buffers per operand, the DMA runs TWO k-tiles ahead and the
 // k-tile boundary waits with a COUNTED `s_waitcnt vmcnt(PA + PB)` — the tile needed next is complete, the one just issued may still be
 // in flight — instead of the full drain a `__syncthreads()` brings (SQ counters: the small tiles park 20 % of their cycles there).
-template <int BM, int BN, int BK, int WM, int WN, bool B_KC, int EPI = 0, int RAGGED = 0, int NBUF = 2>
+// CT: C is addressed with unit stride along rows (a "TT" product run as the swapped NN product, HipExec::gemm): 16-B stores of the
+// four consecutive rows a lane holds. A separate instantiation — as a run-time branch it cost the 256x256 NN kernel its last registers.
+template <int BM, int BN, int BK, int WM, int WN, bool B_KC, int EPI = 0, int RAGGED = 0, int NBUF = 2, bool CT = false>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
   static_assert(NBUF == 2 || (NBUF == 3 && EPI == 0 && RAGGED == 0), "three buffers: plain whole-tile kernel only");
+  static_assert(!CT || (!B_KC && EPI == 0 && RAGGED == 0), "transposed C addressing: whole-tile NN form only");
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / (32 * WM), WTN = BN / (32 * WN);
   constexpr int PA = BM * BK / (4 * NT), PB = BN * BK / (4 * NT), NP = BK / 8, KH = BK / 16;
@@ -916,6 +922,20 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
     constexpr int NPASS = (BM * BN > BM * BK * 4) ? (BM * BN) / (BM * BK * 4) : 1;
     __syncthreads();
     md_epi_bias_relu<BM, BN, WM, WN, NPASS>(acc, g, m0, n0, reinterpret_cast<uint32_t *>(A0), B0);
+    return;
+  }
+  if constexpr (CT) {   // C^T addressing of a swapped TT product: rows are the unit-stride axis
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) {
+        const int64_t col = n0 + wn * (WTN * 32) + j * 32 + l32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t row = m0 + wm * (WTM * 32) + i * 32 + 8 * q + 4 * h;
+          *reinterpret_cast<f32x4 *>(C + row + col * g.c_ns) = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        }
+      }
     return;
   }
 #pragma unroll
@@ -1200,8 +1220,20 @@ static int launch_kc_glds(GemmArgs ga, int64_t batch, bool edge) {
   }
   if constexpr (EPI == 0 && BM <= 128) {
     if (md_gemm_nbuf3((int64_t)grid.x * grid.z, ga.K, BK)) {
+      if constexpr (!B_KC) {
+        if (ga.c_vec_rows) {
+          md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, 0, 0, 3, true>, grid, 64 * WM * WN, ga);
+          return MD_LAUNCH_CHECK("matmul(f32 mfma, direct-to-LDS, 3 buffers, C^T stores)");
+        }
+      }
       md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, 0, 0, 3>, grid, 64 * WM * WN, ga);
       return MD_LAUNCH_CHECK("matmul(f32 mfma, direct-to-LDS, 3 buffers)");
+    }
+  }
+  if constexpr (EPI == 0 && !B_KC) {
+    if (ga.c_vec_rows) {
+      md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, 0, 0, 2, true>, grid, 64 * WM * WN, ga);
+      return MD_LAUNCH_CHECK("matmul(f32 mfma, direct-to-LDS, C^T stores)");
     }
   }
   md_gemm_launch(k_gemm_f32_kc_glds<BM, BN, BK, WM, WN, B_KC, EPI>, grid, 64 * WM * WN, ga);
@@ -1566,9 +1598,24 @@ static int launch_f64_pick(const GemmArgs64 &ga, int64_t batch, bool edge) {
 }
 
 struct HipExec {
-  template <class T> static int gemm(const MdGemm &g) {
-    if (g.batch > 65535) return md_fail(MDHIP_EVALUE, "matmul: batch extent %lld exceeds 65535", (long long)g.batch);
+  template <class T> static int gemm(const MdGemm &g_in) {
+    if (g_in.batch > 65535) return md_fail(MDHIP_EVALUE, "matmul: batch extent %lld exceeds 65535", (long long)g_in.batch);
+    MdGemm g = g_in;
+    bool c_rows_unit = false;
     if constexpr (md_same<T, float>::value) {
+      // "TT" (A^T B^T of two row-major arrays: A unit-stride along m, B along k) has no kernel of its own: C^T = B'A' is the NN
+      // product of the two STORAGES (B' = N x K k-contiguous, A' = K x M row-contiguous), so it runs on the NN direct-to-LDS
+      // kernels with the operands swapped and C addressed through swapped strides; the epilogue then holds four consecutive
+      // elements of a C row per lane and stores them as one 16-B vector (c_vec_rows)
+      const char *tt_env = getenv("MDHIP_GEMM_TT_SWAP");   // (read at every launch: A/B runs and the exactness tests)
+      if (!(tt_env && tt_env[0] == '0') && g.a_ms == 1 && g.a_ks != 1 && g.b_ks == 1 && g.b_ns != 1 && g.M > 1 && g.N > 1 && g.K > 1) {
+        g.a = g_in.b; g.b = g_in.a;
+        g.M = g_in.N; g.N = g_in.M;
+        g.a_bs = g_in.b_bs; g.a_ms = g_in.b_ns; g.a_ks = g_in.b_ks;
+        g.b_bs = g_in.a_bs; g.b_ks = g_in.a_ks; g.b_ns = g_in.a_ms;
+        g.c_ms = g_in.c_ns; g.c_ns = g_in.c_ms;
+        c_rows_unit = g.c_ms == 1 && (g.c_ns & 3) == 0 && (g.c_bs & 3) == 0 && ((uintptr_t)g.c & 15) == 0 && g.M % 4 == 0;
+      }
       // each operand must have a unit stride along k or along its other axis
       const bool a_kc = g.a_ks == 1 || g.K == 1, a_mc = g.a_ms == 1 || g.M == 1;
       const bool b_kc = g.b_ks == 1 || g.K == 1, b_nc = g.b_ns == 1 || g.N == 1;
@@ -1581,6 +1628,7 @@ struct HipExec {
         ga.b_bs = g.b_bs; ga.b_ks = g.b_ks; ga.b_ns = g.b_ns;
         ga.c_bs = g.c_bs; ga.c_ms = g.c_ms; ga.c_ns = g.c_ns;
         ga.tiles_m = ga.tiles_n = 0;  // set per tile config
+        ga.c_vec_rows = c_rows_unit ? 1 : 0;
         // prefer the layout that allows 16-B loads; A_KC means "vectorise A along k"
         const bool A_KC = a_kc && !(a_mc && g.a_ks != 1), B_KC = b_kc && !(b_nc && g.b_ks != 1);
         auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };

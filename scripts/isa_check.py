@@ -112,8 +112,8 @@ def raw_kernels(text):
 
 
 HEADLINE = {
-    "NN 256x256x32": "k_gemm_f32_kc_gldsILi256ELi256ELi32ELi2ELi2ELb0ELi0ELi0ELi2EE",
-    "NT 256x256x32": "k_gemm_f32_kc_gldsILi256ELi256ELi32ELi2ELi2ELb1ELi0ELi0ELi2EE",
+    "NN 256x256x32": "k_gemm_f32_kc_gldsILi256ELi256ELi32ELi2ELi2ELb0ELi0ELi0ELi2ELb0EE",
+    "NT 256x256x32": "k_gemm_f32_kc_gldsILi256ELi256ELi32ELi2ELi2ELb1ELi0ELi0ELi2ELb0EE",
     "TN 256x256x32": "k_gemm_f32_tn_gldsILi256ELi256ELi32ELi2ELi2ELi0ELi2EE",
 }
 

@@ -273,6 +273,35 @@ def test_direct_to_lds_gemm_random_aligned_shapes(lib, on_gpu):
         nd.set_lazy(prev)
 
 
+def test_tt_products_run_as_the_swapped_nn_product(lib, on_gpu, monkeypatch):
+    """x.T @ y.T of two row-major arrays ("TT") has no kernel of its own: C^T = y x is the NN product of the two storages, run on
+    the direct-to-LDS NN kernels with C addressed through swapped strides and stored as 16-B vectors along rows (gemm.hip,
+    HipExec::gemm). Integer-valued operands: every product must EQUAL NumPy's and the register-staged TT kernel's
+    (MDHIP_GEMM_TT_SWAP=0); whole tiles of every size class, three-buffer grids, batches, ragged sizes."""
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    rng = np.random.default_rng(77)
+    prev = nd.set_lazy(False)
+    try:
+        shapes = [(1024, 512, 768, 0), (2048, 256, 2048, 0), (4096, 128, 4096, 0), (512, 384, 256, 3), (1000, 260, 516, 0), (130, 64, 258, 2),
+                  (1024, 1024, 1024, 0)]
+        for (M, K, N, batch) in shapes:
+            lead = (batch,) if batch else ()
+            xa = rng.integers(-3, 4, lead + (K, M)).astype(np.float32)      # A = xa^T
+            xb = rng.integers(-3, 4, lead + (N, K)).astype(np.float32)      # B = xb^T
+            da, db = nd.asarray(xa), nd.asarray(xb)
+            ref = np.matmul(np.swapaxes(xa, -1, -2).astype(np.float64), np.swapaxes(xb, -1, -2).astype(np.float64))
+            monkeypatch.setenv("MDHIP_GEMM_TT_SWAP", "1")
+            got = nd.matmul(nd.swapaxes(da, -1, -2), nd.swapaxes(db, -1, -2))
+            assert got.shape == ref.shape and got.is_c_contiguous
+            assert np.array_equal(got.get(), ref), (M, K, N, batch)
+            monkeypatch.setenv("MDHIP_GEMM_TT_SWAP", "0")
+            old = nd.matmul(nd.swapaxes(da, -1, -2), nd.swapaxes(db, -1, -2))
+            assert np.array_equal(old.get(), ref), (M, K, N, batch)
+    finally:
+        nd.set_lazy(prev)
+
+
 def test_misaligned_operands_of_large_products_are_repacked(lib, on_gpu):
     """Odd leading dimensions (x.T of a matrix with an odd column count) and views that start off a 16-byte boundary: large
     products copy such an operand once into an aligned, row-padded buffer and take the direct-to-LDS kernels (gemm.hip,
