@@ -1152,7 +1152,9 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
 // (128x128x32, 8-wave 256x128 and 256x256 tiles were measured and dropped: profiles/r1_gemm_tile_ab.log, r2_gemm_small_grid_ab.log)
 enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_256x256x32, CFG_128x128x32, CFG_128x64x32, CFG_128x128_W8, CFG_COUNT };
 
-static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged, bool dma_ok = false) {
+// `est` (optional): the model's time for the chosen tile, in units of 512 K / 1e12 seconds (rounds x BM x BN / TFLOP/s)
+static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged, bool dma_ok = false, double *est = nullptr) {
+  if (est) *est = 64.0 * 64.0 / 120.0;   // (the early returns: one round of the small tile, split-K or not)
   if (const char *e = getenv("MDHIP_GEMM_CFG")) {  // experiments only
     int v = atoi(e);
     if (v >= 0 && v < CFG_COUNT) return v;
@@ -1188,6 +1190,7 @@ static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged, bool 
     if (!dma && ((ga.M % c.bm) || (ga.N % c.bn) || (ga.K % 16))) t /= 0.85;
     if (t < best_t * 0.999) { best_t = t; best = c.cfg; }   // ties go to the larger tile (listed first)
   }
+  if (est && best_t < 1e299) *est = best_t;
   return best;
 }
 
@@ -1241,14 +1244,19 @@ static int launch_kc_glds(GemmArgs ga, int64_t batch, bool edge) {
 }
 
 template <bool A_KC, bool B_KC>
-static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
+static bool md_gemm_dma_ok(const GemmArgs &ga, bool edge) {
   // direct-to-LDS kernels: aligned operands whose vector axis has stride 1 (MDHIP_GEMM_GLDS=0, read at every launch, keeps
   // the register-staged kernels: A/B runs and tests)
   const char *e = getenv("MDHIP_GEMM_GLDS");
-  const bool dma_ok = (e ? atoi(e) != 0 : true) && !edge && !ga.stamp && (A_KC ? ga.a_ks == 1 : ga.a_ms == 1) && (B_KC ? ga.b_ks == 1 : ga.b_ns == 1) &&
-                      (A_KC || !B_KC) &&   // (A row-contiguous with B k-contiguous — "TT" — has no such kernel)
-                      // sizes the tiles do not divide: every 16-B piece must lie wholly inside or outside its operand
-                      ((A_KC || B_KC) ? ga.K % 4 == 0 : true) && (A_KC || ga.M % 4 == 0 || ga.pad_m) && (B_KC || ga.N % 4 == 0 || ga.pad_n);
+  return (e ? atoi(e) != 0 : true) && !edge && !ga.stamp && (A_KC ? ga.a_ks == 1 : ga.a_ms == 1) && (B_KC ? ga.b_ks == 1 : ga.b_ns == 1) &&
+         (A_KC || !B_KC) &&   // (A row-contiguous with B k-contiguous — "TT" — has no such kernel: HipExec::gemm swaps it into NN)
+         // sizes the tiles do not divide: every 16-B piece must lie wholly inside or outside its operand
+         ((A_KC || B_KC) ? ga.K % 4 == 0 : true) && (A_KC || ga.M % 4 == 0 || ga.pad_m) && (B_KC || ga.N % 4 == 0 || ga.pad_n);
+}
+
+template <bool A_KC, bool B_KC>
+static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
+  const bool dma_ok = md_gemm_dma_ok<A_KC, B_KC>(ga, edge);
   const int cfg = pick_cfg(ga, batch, !A_KC && !B_KC, dma_ok);
   if constexpr (A_KC) {
     if (dma_ok) {
@@ -1284,6 +1292,55 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
       else return launch_cfg<128, 128, 16, 2, 4, A_KC, B_KC, 1>(ga, batch, edge);
     default: return launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC, 1>(ga, batch, edge);
   }
+}
+
+
+// A product whose M and / or N are a few rows past a multiple of the big tile (x.T of a 4097-column matrix: 4097 x 4096 x 4100)
+// pays for its ragged edge with a whole extra ROUND of tiles in a single launch (17 x 17 tiles of 256^2 for 256.3 tiles of work), or
+// runs everything on small tiles. Peeled instead: the aligned main block [0, Mm) x [0, Nm) on the whole-tile kernels, the bottom strip
+// [Mm, M) x [0, N) and the right strip [0, Mm) x [Nm, N) as two small products (thin strips take the split-K route) — three launches
+// on one stream writing disjoint parts of C. Chosen by the same cost model as the tiles, when it beats the single launch by > 3 %.
+template <bool A_KC, bool B_KC>
+static int launch_mfma_peeled(const GemmArgs &ga, int64_t batch, bool edge) {
+  const char *pe = getenv("MDHIP_GEMM_PEEL");   // (read at every launch: A/B runs and the exactness tests)
+  const int mode = pe ? atoi(pe) : 1;           // 0 never, 1 by the model, 2 whenever there is an edge to peel
+  const int64_t G = 256;
+  const int64_t Mm = ga.M / G * G, Nm = ga.N / G * G, Mr = ga.M - Mm, Nr = ga.N - Nm;
+  if (mode == 0 || edge || ga.stamp || (Mr == 0 && Nr == 0) || Mm == 0 || Nm == 0 || ga.K % 32 || ga.bias) return launch_mfma<A_KC, B_KC>(ga, batch, edge);
+  auto sub = [&](int64_t m0, int64_t m1, int64_t n0, int64_t n1) {
+    GemmArgs x = ga;
+    x.A = ga.A + m0 * ga.a_ms; x.B = ga.B + n0 * ga.b_ns; x.C = ga.C + m0 * ga.c_ms + n0 * ga.c_ns;
+    x.M = m1 - m0; x.N = n1 - n0;
+    if (x.c_vec_rows && (x.M % 4 || ((uintptr_t)x.C & 15))) x.c_vec_rows = 0;
+    return x;
+  };
+  const GemmArgs main_blk = sub(0, Mm, 0, Nm), bottom = sub(Mm, ga.M, 0, ga.N), right = sub(0, Mm, Nm, ga.N);
+  auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+  if (!al16(bottom.A) || !al16(right.B)) return launch_mfma<A_KC, B_KC>(ga, batch, edge);   // (cannot happen for aligned operands: Mm, Nm are multiples of 256)
+  if (mode == 1) {
+    double t_one = 0, t_main = 0, t_b = 0, t_r = 0;
+    pick_cfg(ga, batch, !A_KC && !B_KC, md_gemm_dma_ok<A_KC, B_KC>(ga, edge), &t_one);
+    pick_cfg(main_blk, batch, !A_KC && !B_KC, md_gemm_dma_ok<A_KC, B_KC>(main_blk, edge), &t_main);
+    if (Mr) pick_cfg(bottom, batch, !A_KC && !B_KC, md_gemm_dma_ok<A_KC, B_KC>(bottom, edge), &t_b);
+    if (Nr) pick_cfg(right, batch, !A_KC && !B_KC, md_gemm_dma_ok<A_KC, B_KC>(right, edge), &t_r);
+    const double launch = 6e-6 * 1e12 / (512.0 * (double)ga.K);   // ~6 us per extra launch (prologue / epilogue of a lone small kernel), in model units
+    // the ragged single launch runs ~8 % under the model (4097 x 4096 x 4100: 112 TFLOP/s measured against 123 modelled)
+    if (t_main + t_b + t_r + launch * ((Mr != 0) + (Nr != 0)) > 0.97 * (t_one / 0.92)) return launch_mfma<A_KC, B_KC>(ga, batch, edge);
+  }
+  auto strip = [&](const GemmArgs &x) {   // a strip of up to eight rows / columns is a skinny product (skinny.hip: one read of the big operand)
+    MdGemm sg;
+    sg.batch = batch; sg.M = x.M; sg.N = x.N; sg.K = x.K;
+    sg.a = x.A; sg.b = x.B; sg.c = x.C;
+    sg.a_bs = x.a_bs; sg.a_ms = x.a_ms; sg.a_ks = x.a_ks;
+    sg.b_bs = x.b_bs; sg.b_ks = x.b_ks; sg.b_ns = x.b_ns;
+    sg.c_bs = x.c_bs; sg.c_ms = x.c_ms; sg.c_ns = x.c_ns;
+    const int rc = md_gemm_skinny(sg, MDHIP_F32);
+    return rc >= 0 ? rc : launch_mfma<A_KC, B_KC>(x, batch, edge);
+  };
+  int rc = launch_mfma<A_KC, B_KC>(main_blk, batch, edge);
+  if (rc == MDHIP_OK && Mr) rc = strip(bottom);
+  if (rc == MDHIP_OK && Nr) rc = strip(right);
+  return rc;
 }
 
 
@@ -1600,6 +1657,11 @@ static int launch_f64_pick(const GemmArgs64 &ga, int64_t batch, bool edge) {
 struct HipExec {
   template <class T> static int gemm(const MdGemm &g_in) {
     if (g_in.batch > 65535) return md_fail(MDHIP_EVALUE, "matmul: batch extent %lld exceeds 65535", (long long)g_in.batch);
+    if constexpr (md_same<T, float>::value || md_same<T, double>::value) {
+      // a thin side (matrix x vector, a few columns / rows): HBM-bound streaming kernels (skinny.hip)
+      const int rc = md_gemm_skinny(g_in, md_same<T, float>::value ? MDHIP_F32 : MDHIP_F64);
+      if (rc >= 0) return rc;
+    }
     MdGemm g = g_in;
     bool c_rows_unit = false;
     if constexpr (md_same<T, float>::value) {
@@ -1673,10 +1735,10 @@ struct HipExec {
           edge = false;
         }
         int rc;
-        if (A_KC && B_KC) rc = launch_mfma<true, true>(ga, g.batch, edge);
-        else if (A_KC && !B_KC) rc = launch_mfma<true, false>(ga, g.batch, edge);
-        else if (!A_KC && B_KC) rc = launch_mfma<false, true>(ga, g.batch, edge);
-        else rc = launch_mfma<false, false>(ga, g.batch, edge);
+        if (A_KC && B_KC) rc = launch_mfma_peeled<true, true>(ga, g.batch, edge);
+        else if (A_KC && !B_KC) rc = launch_mfma_peeled<true, false>(ga, g.batch, edge);
+        else if (!A_KC && B_KC) rc = launch_mfma_peeled<false, true>(ga, g.batch, edge);
+        else rc = launch_mfma_peeled<false, false>(ga, g.batch, edge);
         if (tmp_a) mdhip_free(tmp_a);   // stream-ordered: the next user of the block runs after the product
         if (tmp_b) mdhip_free(tmp_b);
         return rc;

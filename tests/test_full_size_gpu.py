@@ -341,6 +341,42 @@ def test_misaligned_operands_of_large_products_are_repacked(lib, on_gpu):
         nd.set_lazy(prev)
 
 
+def test_peeled_ragged_products(lib, on_gpu, monkeypatch):
+    """A product a few rows / columns past a multiple of 256 runs as an aligned main block on the whole-tile kernels plus a bottom
+    and a right strip (gemm.hip, launch_mfma_peeled). Forced here (MDHIP_GEMM_PEEL=2) on every layout, with thin and fat strips,
+    batches, odd leading dimensions (repacked operands) and K that the peel refuses: integer-valued operands, the products must
+    EQUAL NumPy's and the single-launch result (MDHIP_GEMM_PEEL=0)."""
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    rng = np.random.default_rng(256)
+    prev = nd.set_lazy(False)
+    try:
+        shapes = [(257, 64, 260, 0), (513, 96, 512, 0), (512, 128, 516, 0), (640, 64, 300, 2), (1025, 512, 1028, 0), (384, 100, 260, 0), (300, 64, 257, 0)]
+        for (M, K, N, batch) in shapes:
+            lead = (batch,) if batch else ()
+            for lay in ("NN", "NT", "TN", "TT"):
+                def make(rows, cols, transposed):
+                    r, c = (cols, rows) if transposed else (rows, cols)
+                    big = rng.integers(-3, 4, lead + (r, c)).astype(np.float32)
+                    dev = nd.asarray(big)
+                    return (np.swapaxes(big, -1, -2), nd.swapaxes(dev, -1, -2)) if transposed else (big, dev)
+                (ha, da), (hb, db) = make(M, K, lay[0] == "T"), make(K, N, lay[1] == "T")
+                ref = np.matmul(ha.astype(np.float64), hb.astype(np.float64))
+                for mode in ("2", "1", "0"):
+                    monkeypatch.setenv("MDHIP_GEMM_PEEL", mode)
+                    assert np.array_equal(nd.matmul(da, db).get(), ref), (M, K, N, batch, lay, mode)
+        # the model's own choice at the shape the peel exists for (TN, odd M: repacked A, one bottom row, four right columns)
+        monkeypatch.delenv("MDHIP_GEMM_PEEL")
+        M, K, N = 4097, 1024, 4100
+        a = rng.integers(-2, 3, (K, M)).astype(np.float32)
+        b = rng.integers(-2, 3, (K, N)).astype(np.float32)
+        got = nd.matmul(nd.asarray(a).T, nd.asarray(b)).get()
+        ref = a.T.astype(np.float64) @ b.astype(np.float64)
+        assert np.array_equal(got, ref)
+    finally:
+        nd.set_lazy(prev)
+
+
 def test_gemm_whole_tile_shapes_with_unusual_strides(lib, on_gpu):
     """Whole-tile shapes whose operands are flipped (negative strides), broadcast (stride 0) or every-other-row views: the
     direct-to-LDS launchers must either take them correctly or leave them to the register-staged kernel — exact on integers."""

@@ -274,6 +274,50 @@ def test_skinny_matmul_split_k_gpu(lib, on_gpu):
     assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
 
 
+@gpu
+def test_thin_products_streaming_kernels_gpu(lib, on_gpu):
+    """Matrix x vector, vector x matrix and up to eight columns / rows (skinny.hip: one read of the big operand, no matrix cores),
+    both storage orders of the big operand, 1-D and 2-D thin operands, batches, float32 and float64, sizes the 16-B lanes do not
+    divide evenly into strips. Integer-valued operands: the products must EQUAL NumPy's; repeated calls bit-identical."""
+    assert on_gpu
+    rng = np.random.default_rng(88)
+    for dtype in (np.float32, np.float64):
+        for (R, K) in ((1024, 1024), (2052, 516), (4096, 260), (8192, 128), (520, 2048)):
+            a = rng.integers(-3, 4, (R, K)).astype(dtype)
+            A, At = nd.asarray(a), nd.asarray(np.ascontiguousarray(a.T))
+            for nc in (1, 2, 3, 5, 8):
+                v = rng.integers(-3, 4, (K, nc)).astype(dtype)
+                u = rng.integers(-3, 4, (nc, R)).astype(dtype)
+                V, Vt, U = nd.asarray(v), nd.asarray(np.ascontiguousarray(v.T)), nd.asarray(u)
+                ref = a.astype(np.float64) @ v
+                for x in (A, At.T):                       # big operand row-major / transposed view
+                    for y in (V, Vt.T):                   # thin operand as columns / as k-contiguous rows
+                        got = nd.matmul(x, y)
+                        assert got.dtype == dtype and np.array_equal(got.get(), ref), (dtype, R, K, nc)
+                ref2 = u.astype(np.float64) @ a
+                for x in (A, At.T):
+                    got = nd.matmul(U, x)
+                    assert np.array_equal(got.get(), ref2), (dtype, R, K, nc, "thin M")
+                    assert np.array_equal(nd.matmul(U, x).get(), got.get())
+            v1 = rng.integers(-3, 4, (K,)).astype(dtype)
+            assert np.array_equal(nd.matmul(A, nd.asarray(v1)).get(), a.astype(np.float64) @ v1)
+            w1 = rng.integers(-3, 4, (R,)).astype(dtype)
+            assert np.array_equal(nd.matmul(nd.asarray(w1), A).get(), w1.astype(np.float64) @ a)
+    # batched, and a strided thin operand (a column of a wider matrix)
+    t = rng.integers(-3, 4, (3, 1024, 512)).astype(np.float32)
+    wide = rng.integers(-3, 4, (3, 512, 10)).astype(np.float32)
+    got = nd.matmul(nd.asarray(t), nd.asarray(wide)[:, :, 3:5])
+    assert np.array_equal(got.get(), t.astype(np.float64) @ wide[:, :, 3:5])
+    got = nd.matmul(nd.swapaxes(nd.asarray(wide)[:, :, 3:5], -1, -2), nd.swapaxes(nd.asarray(t), -1, -2))
+    assert np.array_equal(got.get(), np.swapaxes(wide[:, :, 3:5], -1, -2).astype(np.float64) @ np.swapaxes(t, -1, -2))
+    # float data at full size against float64
+    a = rng.standard_normal((8192, 4096)).astype(np.float32)
+    v = rng.standard_normal((4096, 1)).astype(np.float32)
+    ref = a.astype(np.float64) @ v
+    for x in (nd.asarray(a), nd.asarray(np.ascontiguousarray(a.T)).T):
+        got = nd.matmul(x, nd.asarray(v)).get()
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
+
 
 def test_ragged_matmul_cpu(lib, on_gpu):
     if on_gpu:
