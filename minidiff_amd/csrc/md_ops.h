@@ -425,12 +425,11 @@ template <bool IsMax> struct RArg {
   template <class T> static MD_HD md_argpair<T> identity() {
     return md_argpair<T>{IsMax ? md_lowest<T>() : md_highest<T>(), INT64_MAX};
   }
-  template <class T> static MD_HD bool better(T a, T b) {  // a strictly better than b
-    if constexpr (md_is_float<T>::value) {
-      if (a != a) return !(b != b);
-      if (b != b) return false;
-    }
-    return IsMax ? (a > b) : (a < b);
+  template <class T> static MD_HD bool better(T a, T b) {  // a strictly better than b; a NaN beats everything but a NaN
+    // (one expression, no early returns: in the column walk of the arg-reductions the branchy form became an exec-mask branch
+    // per ELEMENT — 442 s_and_saveexec in k_arg_cols_strips<float>)
+    if constexpr (md_is_float<T>::value) return (IsMax ? (a > b) : (a < b)) | ((a != a) & (b == b));
+    else return IsMax ? (a > b) : (a < b);
   }
   template <class T> static MD_HD md_argpair<T> combine(md_argpair<T> a, md_argpair<T> b) {
     if (b.i == INT64_MAX) return a;

@@ -604,6 +604,135 @@ __global__ void __launch_bounds__(MD_BLOCK) k_arg_cols_finish(const T *pval, con
   out[o] = a.i;
 }
 
+// The same walk as k_reduce_cols_strips for (value, row) pairs: NS strips of 64 lanes x 16 B of columns, NB bands of rows, rows
+// interleaved across bands and the block's four waves (a lane meets its rows in increasing order, so "strictly better" keeps the
+// first of equal values and the first NaN, as np.argmax does), batches of RB rows double-buffered; band partials (value + row)
+// published write-through, merged in band order by the block that arrives last at the strip's ticket. One launch (the chunked
+// kernel above + its finish pass ran at 1.5 TB/s on 8192 x 4096: 128 rows per block, four loads in flight per wave).
+// Rows are carried as 32-bit (16-byte T) or 64-bit (8-byte T) integers so that a lane's V rows fill one 16-B vector; n_red < 2^31.
+template <bool IsMax, class T, int RB>
+__global__ void __launch_bounds__(MD_BLOCK) k_arg_cols_strips(const T *__restrict__ x, int64_t n_out, int64_t n_red, int64_t rs, int NS, int NB,
+                                                             T *pval, void *pidx_, unsigned *tickets, int64_t *__restrict__ out) {
+  constexpr int V = 16 / sizeof(T);
+  typedef MdVec<T, V> Vec;
+  typedef typename md_cond<V == 4, int32_t, int64_t>::type I;
+  typedef MdVec<I, V> IVec;
+  static_assert(sizeof(IVec) == 16, "a lane's rows travel as one 16-B vector");
+  __shared__ Vec sv[3][64];
+  __shared__ IVec si[3][64];
+  __shared__ unsigned last_flag;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int s = blockIdx.x % NS, b = blockIdx.x / NS;
+  const int64_t col_raw = ((int64_t)s * 64 + lane) * V;
+  const bool col_ok = col_raw < n_out;
+  const int64_t col = col_ok ? col_raw : n_out - V;
+  const int64_t first = b + (int64_t)NB * w, step = (int64_t)NB * 4;
+  const int64_t nrw = first < n_red ? (n_red - first + step - 1) / step : 0;
+  const int64_t nb = nrw / RB;
+  T bv[V];
+  I bi[V];
+  // bv starts at the identity (lowest / highest value), bi at -1 = "none": an element updates iff it is strictly better — no
+  // "first element" test per element. A lane whose rows all EQUAL the identity (a column of -inf) never updates; it is given its
+  // first row afterwards, which is what the element-by-element rule would have kept.
+#pragma unroll
+  for (int j = 0; j < V; ++j) { bv[j] = RArg<IsMax>::template identity<T>().v; bi[j] = (I)-1; }
+  // (selects, not branches: see k_arg_rows_vec)
+  auto take = [&](const Vec &t, I r) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const bool up = RArg<IsMax>::better(t.v[j], bv[j]);
+      bv[j] = up ? t.v[j] : bv[j];
+      bi[j] = up ? r : bi[j];
+    }
+  };
+  const T *p = x + col + first * rs;
+  const int64_t rstep = step * rs;
+  Vec t[2][RB];
+  auto load = [&](int buf, int64_t bt) {
+    const int64_t i0 = (bt < nb ? bt : nb - 1) * RB;
+#pragma unroll
+    for (int u = 0; u < RB; ++u) t[buf][u] = *reinterpret_cast<const Vec *>(p + (i0 + u) * rstep);
+  };
+  auto eat = [&](int buf, int64_t bt) {
+#pragma unroll
+    for (int u = 0; u < RB; ++u) take(t[buf][u], (I)(first + step * (bt * RB + u)));
+  };
+  if (nb > 0) {
+    load(0, 0);
+    int64_t bt = 0;
+    for (; bt + 1 < nb; bt += 2) {
+      load(1, bt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      eat(0, bt);
+      __builtin_amdgcn_sched_barrier(0);
+      load(0, bt + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      eat(1, bt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (bt < nb) eat(0, bt);
+  }
+  for (int64_t i = nb * RB; i < nrw; ++i) take(*reinterpret_cast<const Vec *>(p + i * rstep), (I)(first + step * i));
+  if (nrw > 0) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) bi[j] = bi[j] < 0 ? (I)first : bi[j];
+  }
+  auto merge = [&](const Vec &ov, const IVec &oi) {   // (value, row) pairs of another wave / band into this lane's
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const md_argpair<T> a = RArg<IsMax>::combine(md_argpair<T>{bv[j], bi[j] < 0 ? INT64_MAX : (int64_t)bi[j]},
+                                                  md_argpair<T>{ov.v[j], oi.v[j] < 0 ? INT64_MAX : (int64_t)oi.v[j]});
+      bv[j] = a.v;
+      bi[j] = a.i == INT64_MAX ? (I)-1 : (I)a.i;
+    }
+  };
+  auto pack = [&](Vec &ov, IVec &oi) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) { ov.v[j] = bv[j]; oi.v[j] = bi[j]; }
+  };
+  if (w > 0) pack(sv[w - 1][lane], si[w - 1][lane]);
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) merge(sv[k][lane], si[k][lane]);
+  }
+  auto store_out = [&]() {
+#pragma unroll
+    for (int j = 0; j < V; ++j) out[col + j] = bi[j] < 0 ? INT64_MAX : (int64_t)bi[j];
+  };
+  if (NB == 1) {
+    if (w == 0 && col_ok) store_out();
+    return;
+  }
+  I *pidx = (I *)pidx_;
+  const __amdgpu_buffer_rsrc_t prv = md_rsrc(pval, (unsigned)((int64_t)NB * n_out * (int64_t)sizeof(T)));
+  const __amdgpu_buffer_rsrc_t pri = md_rsrc(pidx, (unsigned)((int64_t)NB * n_out * (int64_t)sizeof(I)));
+  if (w == 0 && col_ok) {
+    Vec ov;
+    IVec oi;
+    pack(ov, oi);
+    md_st16_sc1(prv, (unsigned)(((int64_t)b * n_out + col) * (int64_t)sizeof(T)), ov);
+    md_st16_sc1(pri, (unsigned)(((int64_t)b * n_out + col) * (int64_t)sizeof(I)), oi);
+  }
+  if (!md_ticket_last(tickets + s * MD_TICKET_PAD, (unsigned)NB, &last_flag)) return;
+  // the strip's NB partial rows: wave w takes bands w, w + 4, .. in increasing order; then the waves in wave order
+#pragma unroll
+  for (int j = 0; j < V; ++j) { bv[j] = T(); bi[j] = (I)-1; }
+  for (int r = w; r < NB; r += 4) {
+    const Vec ov = md_ld16_sc1<Vec>(prv, (unsigned)(((int64_t)r * n_out + col) * (int64_t)sizeof(T)));
+    const IVec oi = md_ld16_sc1<IVec>(pri, (unsigned)(((int64_t)r * n_out + col) * (int64_t)sizeof(I)));
+    merge(ov, oi);
+  }
+  __syncthreads();
+  if (w > 0) pack(sv[w - 1][lane], si[w - 1][lane]);
+  __syncthreads();
+  if (w == 0 && col_ok) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) merge(sv[k][lane], si[k][lane]);
+    store_out();
+  }
+}
+
 static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 struct HipExec {
@@ -743,6 +872,28 @@ struct HipExec {
           (pl.rx[0] % V) == 0 && ((uintptr_t)x->data & 15) == 0 && pl.n_red >= 16) {
         const int64_t n_out = pl.n_out, n_red = pl.n_red;
         const int64_t bxv = ceil_div(n_out, 64 * V);
+        static const bool strips_on = [] { const char *e = getenv("MDHIP_ARG_STRIPS"); return !(e && e[0] == '0'); }();   // 0: the chunked kernel + finish pass (A/B)
+        if (strips_on && n_red < (1ll << 31) && n_red >= 64 && bxv * MD_TICKET_PAD <= MD_TICKET_WORDS) {
+          const int64_t NS = bxv;
+          int64_t NB = ceil_div(1024, NS);
+          if (NB > 64) NB = 64;
+          if (NB > n_red / 32) NB = n_red / 32;
+          if (NB < 1) NB = 1;
+          while (NB > 1 && NB * n_out * 8 >= (1ll << 31)) NB /= 2;   // (32-bit byte offsets into the partial rows)
+          constexpr int ARG_RB = 4;   // (8 rows per batch: 135-141 registers, three waves per SIMD; 4: four waves)
+          void *pv = nullptr, *pi = nullptr;
+          if (NB > 1) {
+            MD_TRY(mdhip_alloc((size_t)(NB * n_out) * sizeof(T), &pv));
+            const int rc = mdhip_alloc((size_t)(NB * n_out) * (V == 4 ? 4 : 8), &pi);
+            if (rc != MDHIP_OK) { mdhip_free(pv); return rc; }
+          }
+          MD_LAUNCH((k_arg_cols_strips<IsMax, T, ARG_RB>), (unsigned)(NS * NB), MD_BLOCK, (const T *)x->data, n_out, n_red, pl.rx[0], (int)NS, (int)NB, (T *)pv, pi, md_tickets(),
+                    (int64_t *)out->data);
+          const int rc = MD_LAUNCH_CHECK("argreduce(cols,strips)");
+          if (pv) mdhip_free(pv);
+          if (pi) mdhip_free(pi);
+          return rc;
+        }
         int64_t splits = 1024 / bxv;
         if (splits > n_red / 64) splits = n_red / 64;
         if (splits > 65535) splits = 65535;

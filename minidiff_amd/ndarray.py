@@ -37,9 +37,18 @@ from ._capi import ArrayDesc, IndexPlan, MAX_NDIM
 if os.environ.get("MDHIP_FASTPATH", "1") != "0" and not os.environ.get("MDHIP_TRACE"):
     try:
         from . import _fastpath as _fp
-    except ImportError as e:  # built by `make -C minidiff_amd/csrc` next to libmdhip.so
-        raise ImportError(f"minidiff_amd/_fastpath extension is missing ({e}): run `python -c 'import __graft_entry__ as g; g.build()'` "
-                          "or set MDHIP_FASTPATH=0 for the pure-Python host path") from e
+    except ImportError as e:  # built by `make -C minidiff_amd/csrc` next to libmdhip.so; host-only C, one gcc call: build it now
+        import subprocess
+        import sysconfig
+        _here = os.path.dirname(os.path.abspath(__file__))
+        _target = "../_fastpath" + sysconfig.get_config_var("EXT_SUFFIX")
+        _r = subprocess.run(["make", "-C", os.path.join(_here, "csrc"), _target], capture_output=True, text=True)
+        if _r.returncode != 0:
+            raise ImportError(f"minidiff_amd/_fastpath extension is missing ({e}) and could not be built: {_r.stderr[-500:]}\n"
+                              "run `python -c 'import __graft_entry__ as g; g.build()'` or set MDHIP_FASTPATH=0 for the pure-Python host path") from e
+        import importlib
+        importlib.invalidate_caches()
+        from . import _fastpath as _fp
     if _fp.ABI_DESC_BYTES != C.sizeof(ArrayDesc):
         raise ImportError("minidiff_amd/_fastpath was built against another include/mdhip.h: rebuild (make -C minidiff_amd/csrc)")
 else:
