@@ -236,6 +236,14 @@ int mdhip_random_permutation(uint64_t seed, uint64_t offset, const mdhip_array *
  * the (single, or fully flattened) reduced extent.
  * (reference: numpy.py:20-23,43-46,57; reduce-to-shape definitions.py:157-183) */
 int mdhip_reduce(int op, const mdhip_array *x, const mdhip_array *out, uint32_t axis_mask);
+/* Variance / standard deviation along ONE axis in a single entry point. NumPy's np.std (numpy.py:57, called by definitions.py:209-221
+ * in the forward pass and again in the vjp) is mean -> x - mean -> square -> sum -> divide -> sqrt: four reads and two writes of the
+ * array when composed from the entry points above; this is one read (rows) or two (columns), same arithmetic up to the order of the
+ * two sums. x: float32 / float64, C-contiguous, 16-B aligned; the reduced axis must be the last one (row length a multiple of 16 B)
+ * or, for a 2-D view (n, inner), the first (inner >= 256 and a multiple of 16 B, n >= 64). out: C-contiguous, x's dtype, one element
+ * per kept position; result = sum((x - mean)^2) / (n - ddof), square-rooted when take_sqrt != 0. Requires n - ddof > 0.
+ * Any other form returns MDHIP_EVALUE and the caller composes the result from the other entry points (as NumPy does). */
+int mdhip_var(const mdhip_array *x, const mdhip_array *out, int32_t axis, int64_t ddof, int take_sqrt);
 
 /* ======================= matmul =========================================== */
 /* C[b] = A[b] @ B[b]: A (batch.., M, K), B (batch.., K, N), C (batch.., M, N),

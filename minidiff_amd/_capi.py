@@ -120,6 +120,7 @@ _PROTOTYPES = {
     "mdhip_fill": [_P(ArrayDesc), _P(ArrayDesc)],
     "mdhip_arange": [_P(ArrayDesc), C.c_double, C.c_double],
     "mdhip_reduce": [C.c_int, _P(ArrayDesc), _P(ArrayDesc), C.c_uint32],
+    "mdhip_var": [_P(ArrayDesc), _P(ArrayDesc), C.c_int32, C.c_int64, C.c_int],
     "mdhip_matmul": [_P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc)],
     "mdhip_matmul_bias_relu_sum": [_P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc), _P(ArrayDesc)],
     "mdhip_gather": [_P(IndexPlan), C.c_void_p, C.c_int, _P(ArrayDesc)],

@@ -1715,12 +1715,47 @@ def mean(a, axis=None, dtype=None, out=None, keepdims=False, **_):
     return _binary(np.true_divide, _capi.B_TRUE_DIV, s, n, out=s)
 
 
+def _std_fused(a, axis, dtype, ddof, keepdims, n):
+    """One-pass (rows) / two-pass (columns) kernel for the forms mdhip_var covers: a concrete float32 / float64 C-contiguous array
+    reduced over its last axis, or a 2-D one over its first; anything else -> None and `std` composes NumPy's five steps."""
+    if a._code not in _FLOAT_CODES or a._expr is not None or (dtype is not None and np.dtype(dtype) != a.dtype) or a.ndim == 0:
+        return None
+    if isinstance(axis, (tuple, list)):
+        if len(axis) != 1:
+            return None
+        axis = axis[0]
+    if axis is None:
+        if a.ndim != 1:
+            return None
+        axis = 0
+    if not isinstance(axis, (int, np.integer)) or isinstance(axis, py_bool) or not isinstance(ddof, (int, np.integer)) or isinstance(ddof, py_bool):
+        return None
+    ax = int(axis)
+    if ax < -a.ndim or ax >= a.ndim:
+        return None          # (the composed path raises NumPy's AxisError)
+    ax %= a.ndim
+    if n - int(ddof) <= 0 or n < 2 or not a.is_c_contiguous or a.size == 0:
+        return None
+    if not (ax == a.ndim - 1 or (ax == 0 and a.ndim == 2)):
+        return None
+    kshape = a.shape[:ax] + (1,) + a.shape[ax + 1:]
+    res = DeviceArray._new(kshape, a.dtype)
+    try:
+        _lib().var(a.desc(), res.desc(), ax, int(ddof), 1)
+    except ValueError:       # a form the kernel leaves to the composition (alignment, short / narrow shapes)
+        return None
+    return res if keepdims else reshape(res, a.shape[:ax] + a.shape[ax + 1:])
+
+
 def std(a, axis=None, dtype=None, out=None, ddof=0, keepdims=False, **_):
     # numpy/_core/_methods.py:_var/_std — mean, centred squares, mean, sqrt
     a = asarray(a)
     n = _count(a, axis)
     if dtype is None and a.dtype.kind in "bi":
         dtype = np.dtype(np.float64)
+    fused = _std_fused(a, axis, dtype, ddof, keepdims, n)
+    if fused is not None:
+        return fused
     arrmean = sum(a, axis=axis, dtype=dtype, keepdims=True)
     arrmean = _binary(np.true_divide, _capi.B_TRUE_DIV, arrmean, n, out=arrmean)
     x = subtract(a, arrmean)

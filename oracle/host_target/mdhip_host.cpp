@@ -12,6 +12,7 @@
 // It shares csrc/md_ops.h + md_dispatch.h with the device build, so dispatch
 // and per-element semantics are the same code; the loops below are the naive
 // sequential restatement (no tiling, no vectorisation, k-ordered accumulation).
+#include <cmath>
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -300,6 +301,59 @@ int mdhip_random_permutation(uint64_t seed, uint64_t offset, const mdhip_array *
 }
 int mdhip_reduce(int op, const mdhip_array *x, const mdhip_array *out, uint32_t mask) {
   return md_reduce_dispatch<HostExec>(op, x, out, mask);
+}
+// variance / std along one axis: NumPy's _var spelled out (mean by a true division, centred squares, division, sqrt), sequential sums.
+// Same covered forms as the product (so that both the fused call and the composed fallback get exercised on the CPU too).
+}  // extern "C"
+template <class T> static void host_var(const T *x, int64_t outer, int64_t n, int64_t inner, T *out, T denom, int take_sqrt) {
+  for (int64_t o = 0; o < outer; ++o)
+    for (int64_t i = 0; i < inner; ++i) {
+      const T *p = x + o * n * inner + i;
+      T s = 0;
+      for (int64_t k = 0; k < n; ++k) s += p[k * inner];
+      const T mean = s / (T)n;
+      T q = 0;
+      for (int64_t k = 0; k < n; ++k) { const T d = p[k * inner] - mean; q += d * d; }
+      const T v = q / denom;
+      out[o * inner + i] = take_sqrt ? std::sqrt(v) : v;
+    }
+}
+extern "C" {
+int mdhip_var(const mdhip_array *x, const mdhip_array *out, int32_t axis, int64_t ddof, int take_sqrt) {
+  MD_TRY(md_check_array(x, "var x"));
+  MD_TRY(md_check_array(out, "var out"));
+  if (x->is_scalar || out->is_scalar) return md_fail(MDHIP_EVALUE, "var: arrays expected");
+  if (x->dtype != MDHIP_F32 && x->dtype != MDHIP_F64) return md_fail(MDHIP_EVALUE, "var: float32 / float64 only (the caller composes the rest)");
+  if (out->dtype != x->dtype) return md_fail(MDHIP_ETYPE, "var: out dtype must equal x dtype");
+  if (axis < 0 || axis >= x->ndim) return md_fail(MDHIP_EVALUE, "var: axis out of range");
+  int64_t acc = 1, outer = 1, inner = 1;
+  for (int d = x->ndim - 1; d >= 0; --d) {
+    if (x->shape[d] != 1 && x->strides[d] != acc) return md_fail(MDHIP_EVALUE, "var: x is not C-contiguous");
+    acc *= x->shape[d];
+    if (d > axis) inner *= x->shape[d];
+    if (d < axis) outer *= x->shape[d];
+  }
+  const int64_t n = x->shape[axis];
+  if (n - ddof <= 0 || n < 2 || outer * inner == 0) return md_fail(MDHIP_EVALUE, "var: degenerate count (the caller composes NumPy's nan / inf)");
+  int64_t osz = 1, oacc = 1;
+  for (int d = out->ndim - 1; d >= 0; --d) {
+    if (out->shape[d] != 1 && out->strides[d] != oacc) return md_fail(MDHIP_EVALUE, "var: out is not C-contiguous");
+    oacc *= out->shape[d];
+    osz *= out->shape[d];
+  }
+  if (osz != outer * inner) return md_fail(MDHIP_EVALUE, "var: out has the wrong number of elements");
+  const int64_t V = x->dtype == MDHIP_F32 ? 4 : 2;
+  if (((uintptr_t)x->data & 15) || ((uintptr_t)out->data & 15)) return md_fail(MDHIP_EVALUE, "var: unaligned operands");
+  if (inner == 1) {
+    if (n % V) return md_fail(MDHIP_EVALUE, "var: row length not a multiple of the 16-B vector");
+  } else if (outer == 1) {
+    if ((inner % V) || n < 64 || inner < 256) return md_fail(MDHIP_EVALUE, "var: column form needs >= 256 aligned columns and >= 64 rows");
+  } else {
+    return md_fail(MDHIP_EVALUE, "var: reduced axis in the middle (the caller composes)");
+  }
+  if (x->dtype == MDHIP_F32) host_var<float>((const float *)x->data, outer, n, inner, (float *)out->data, (float)(n - ddof), take_sqrt);
+  else host_var<double>((const double *)x->data, outer, n, inner, (double *)out->data, (double)(n - ddof), take_sqrt);
+  return MDHIP_OK;
 }
 int mdhip_matmul(const mdhip_array *a, const mdhip_array *b, const mdhip_array *c) {
   ProfScope prof(a && a->dtype == MDHIP_F32);

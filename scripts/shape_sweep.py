@@ -49,6 +49,7 @@ def main():
         ("argmax axis=0", lambda: nd.argmax(z, axis=0), E),
         ("mean axis=0", lambda: nd.mean(z, axis=0), E),
         ("std axis=1", lambda: nd.std(z, axis=1), E),
+        ("std axis=0", lambda: nd.std(z, axis=0), E),
         ("sum 3d axis=1 (middle)", lambda: nd.sum(t3, axis=1), 4 * t3.size),
         ("sum 3d axis=(0,2)", lambda: nd.sum(t3, axis=(0, 2)), 4 * t3.size),
         ("sum 3d axis=2", lambda: nd.sum(t3, axis=2), 4 * t3.size),

@@ -244,6 +244,18 @@ def one_case(rng, big):
             fdt = np.float32 if rng.random() < 0.5 else np.float64
             lim = 300 if big else 40
             M, K, N = (int(x) for x in rng.integers(1, lim, 3))
+            if big and rng.random() < 0.35:
+                # the shape classes with kernels of their own: a thin side (skinny.hip), sizes a few past a multiple of 256 (peeled
+                # products), whole direct-to-LDS tiles
+                fam = rng.choice(["thin_n", "thin_m", "peel", "tiles"])
+                if fam == "thin_n":
+                    M, K, N = int(rng.choice([512, 1000, 1024, 2052, 4096])), int(rng.choice([64, 260, 512, 1024, 2048])), int(rng.integers(1, 9))
+                elif fam == "thin_m":
+                    M, K, N = int(rng.integers(1, 9)), int(rng.choice([64, 260, 512, 1024, 2048])), int(rng.choice([512, 1000, 1024, 2052, 4096]))
+                elif fam == "peel":
+                    M, K, N = int(rng.choice([256, 512, 768])) + int(rng.integers(0, 10)), 32 * int(rng.integers(1, 9)), int(rng.choice([256, 512, 768])) + int(rng.integers(0, 10))
+                else:
+                    M, K, N = (int(rng.choice([128, 256, 384, 512])) for _ in range(3))
             a = rng.standard_normal((M, K)).astype(fdt)
             b = rng.standard_normal((K, N)).astype(fdt)
             A, B = nd.asarray(a), nd.asarray(b)
