@@ -129,6 +129,41 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows(MdRedPlan pl, const vo
   }
 }
 
+// SHORT contiguous rows (softmax / layer-norm style sums over a last axis of <= 64 * V * NV elements): a WAVE per output, four
+// outputs per block, all of a lane's 16-B loads issued before the first combine. The block-per-output kernel above gives such a
+// row 256 threads for at most a few loads each and one block launch per 4 KiB (64 x 512 x 1024 summed over the last axis: 3.5 TB/s).
+template <class R, class Tacc, class Tdst, int NV>
+__global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows_wave(MdRedPlan pl, const Tacc *__restrict__ x, Tdst *__restrict__ dst) {
+  constexpr int V = 16 / sizeof(Tacc);
+  typedef MdVec<Tacc, V> Vec;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t o = (int64_t)blockIdx.x * 4 + w;
+  if (o >= pl.n_out) return;
+  int64_t xo, oo;
+  md_red_kept_offsets(pl, o, &xo, &oo);
+  const Tacc *p = x + xo;
+  const Vec *pv = reinterpret_cast<const Vec *>(p);
+  const int64_t n = pl.n_red, nvec = n / V;
+  Vec t[NV];
+#pragma unroll
+  for (int g = 0; g < NV; ++g) {
+    const int64_t i = lane + 64 * g;
+    if (i < nvec) t[g] = pv[i];
+  }
+  Tacc acc = R::template identity<Tacc>();
+#pragma unroll
+  for (int g = 0; g < NV; ++g) {
+    if (lane + 64 * g < nvec) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc = R::combine(acc, t[g].v[j]);
+    }
+  }
+  const int64_t t0 = nvec * V;
+  if (t0 + lane < n) acc = R::combine(acc, p[t0 + lane]);
+  acc = md_wave_reduce<R>(acc);
+  if (lane == 0) dst[oo] = md_cast<Tdst>(acc);
+}
+
 // Full reduction of a contiguous array of the accumulator's own type (the loss `sum` of the BASELINE graphs): the rows
 // kernel above without its plan — a lane strides the 16-B vectors of the whole grid, two in flight — and the ticket finish
 // (md_ticket.h, two-level: ~1000 blocks arrive). 24.0 -> 22.5 us on cfg4's 128 MiB against the general kernel: the plan's
@@ -742,6 +777,24 @@ struct HipExec {
     const int64_t n_out = pl.n_out, n_red = pl.n_red;
     const bool rows_ok = n_red >= 256 && n_out < (1ll << 30);
     const bool cols_ok = pl.nk >= 1 && pl.kx[pl.nk - 1] == 1 && n_out >= 64;
+    if constexpr (sizeof(Tacc) >= 4) {
+      // many short contiguous rows: a wave per output (every row must start on a 16-B boundary)
+      constexpr int V = 16 / sizeof(Tacc);
+      static const bool wave_on = [] { const char *e = getenv("MDHIP_ROWS_WAVE"); return !(e && e[0] == '0'); }();   // 0: block per output (A/B)
+      bool aligned = ((uintptr_t)x->data & 15) == 0;
+      for (int k = 0; k < pl.nk; ++k) aligned = aligned && (pl.kx[k] % V) == 0;
+      if (wave_on && pl.nr == 1 && pl.rx[0] == 1 && x->dtype == md_dtype_of<Tacc>::value && aligned && n_red >= 32 && n_red <= 64 * V * 8 &&
+          n_out >= 1024 && n_out < (1ll << 32)) {
+        const unsigned grid = (unsigned)ceil_div(n_out, 4);
+        const Tacc *xp = (const Tacc *)x->data;
+        const int64_t nvec = n_red / V;
+        if (nvec <= 64) MD_LAUNCH((k_reduce_rows_wave<R, Tacc, To, 1>), grid, MD_BLOCK, pl, xp, (To *)out->data);
+        else if (nvec <= 128) MD_LAUNCH((k_reduce_rows_wave<R, Tacc, To, 2>), grid, MD_BLOCK, pl, xp, (To *)out->data);
+        else if (nvec <= 256) MD_LAUNCH((k_reduce_rows_wave<R, Tacc, To, 4>), grid, MD_BLOCK, pl, xp, (To *)out->data);
+        else MD_LAUNCH((k_reduce_rows_wave<R, Tacc, To, 8>), grid, MD_BLOCK, pl, xp, (To *)out->data);
+        return MD_LAUNCH_CHECK("reduce(rows,wave)");
+      }
+    }
     if (cols_ok && (!rows_ok || n_out >= 1024)) {
       if constexpr (sizeof(Tacc) >= 4 && md_same<Tacc, To>::value) {
         constexpr int V = 16 / sizeof(Tacc);
