@@ -91,6 +91,18 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows(MdRedPlan pl, const vo
       for (int j = 0; j < V; ++j) { a2[j] = R::template identity<Tacc>(); a3[j] = a2[j]; }
       const MdVec<Tacc, V> *pv = reinterpret_cast<const MdVec<Tacc, V> *>(p + head);
       int64_t i = lane0;
+      // four loads in flight per lane while the row lasts (a 256-KiB row on two blocks: 2 x 256 lanes x 2 loads left the CU with
+      // 16 KiB in flight — the bn-style sum over (0, 2, 3) of 32 x 16 x 256 x 256 ran at 3.7 TB/s), then two, then one
+      for (; i + 3 * step < nvec; i += 4 * step) {
+        MdVec<Tacc, V> t = md_ld_once<NT>(pv + i);
+        MdVec<Tacc, V> u = md_ld_once<NT>(pv + i + step);
+        MdVec<Tacc, V> t2 = md_ld_once<NT>(pv + i + 2 * step);
+        MdVec<Tacc, V> u2 = md_ld_once<NT>(pv + i + 3 * step);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { a2[j] = R::combine(a2[j], t.v[j]); a3[j] = R::combine(a3[j], u.v[j]); }
+#pragma unroll
+        for (int j = 0; j < V; ++j) { a2[j] = R::combine(a2[j], t2.v[j]); a3[j] = R::combine(a3[j], u2.v[j]); }
+      }
       for (; i + step < nvec; i += 2 * step) {
         MdVec<Tacc, V> t = md_ld_once<NT>(pv + i);
         MdVec<Tacc, V> u = md_ld_once<NT>(pv + i + step);
@@ -332,13 +344,20 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_cols_vec(const Tacc *__rest
 // data, fixed order: bit-identical from run to run.
 template <class R, class Tacc, int RB, bool NT>
 __global__ void __launch_bounds__(MD_BLOCK) k_reduce_cols_strips(const Tacc *__restrict__ x, int64_t n_out, int64_t n_red, int64_t rs, int NS,
-                                                                int NB, Tacc *partial, unsigned *tickets, Tacc *__restrict__ out) {
+                                                                int NB, Tacc *partial, unsigned *tickets, Tacc *__restrict__ out,
+                                                                int64_t x_bs, int64_t o_bs) {
   constexpr int V = 16 / sizeof(Tacc);
   typedef MdVec<Tacc, V> Vec;
   __shared__ Vec sm[3][64];
   __shared__ unsigned last_flag;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int s = blockIdx.x % NS, b = blockIdx.x / NS;
+  // blockIdx.y: one of several independent (n_red x n_out) problems x_bs / o_bs elements apart (a MIDDLE axis reduced: sum over the
+  // sequence axis of (batch, seq, hidden)); each has its own partial rows and its own strip tickets
+  x += (int64_t)blockIdx.y * x_bs;
+  out += (int64_t)blockIdx.y * o_bs;
+  if (NB > 1) partial += (int64_t)blockIdx.y * NB * n_out;
+  tickets += (int64_t)blockIdx.y * NS * MD_TICKET_PAD;
   const int64_t col_raw = ((int64_t)s * 64 + lane) * V;
   const bool col_ok = col_raw < n_out;
   const int64_t col = col_ok ? col_raw : n_out - V;  // lanes past a ragged edge load a valid vector and store nothing
@@ -820,12 +839,35 @@ struct HipExec {
           if (NB > 1) MD_TRY(mdhip_alloc((size_t)(NB * n_out) * sizeof(Tacc), &partial));
           const Tacc *xp = (const Tacc *)x->data;
           if (n_red * n_out * (int64_t)sizeof(Tacc) > ((int64_t)320 << 20))
-            MD_LAUNCH((k_reduce_cols_strips<R, Tacc, RB, true>), (unsigned)(NS * NB), MD_BLOCK, xp, n_out, n_red, pl.rx[0], (int)NS, (int)NB, (Tacc *)partial, md_tickets(), (Tacc *)out->data);
+            MD_LAUNCH((k_reduce_cols_strips<R, Tacc, RB, true>), (unsigned)(NS * NB), MD_BLOCK, xp, n_out, n_red, pl.rx[0], (int)NS, (int)NB, (Tacc *)partial, md_tickets(), (Tacc *)out->data, (int64_t)0, (int64_t)0);
           else
-            MD_LAUNCH((k_reduce_cols_strips<R, Tacc, RB, false>), (unsigned)(NS * NB), MD_BLOCK, xp, n_out, n_red, pl.rx[0], (int)NS, (int)NB, (Tacc *)partial, md_tickets(), (Tacc *)out->data);
+            MD_LAUNCH((k_reduce_cols_strips<R, Tacc, RB, false>), (unsigned)(NS * NB), MD_BLOCK, xp, n_out, n_red, pl.rx[0], (int)NS, (int)NB, (Tacc *)partial, md_tickets(), (Tacc *)out->data, (int64_t)0, (int64_t)0);
           int rc = MD_LAUNCH_CHECK("reduce(cols,strips)");
           if (partial) mdhip_free(partial);  // stream-ordered: the next user of this block runs after the kernel
           return rc;
+        }
+        // a middle axis reduced: (outer, n_red, inner) with the inner axis contiguous — `outer` independent column problems in one launch
+        if constexpr (cheap) {
+          if (sweep_mode && pl.nk == 2 && pl.nr == 1 && pl.kx[1] == 1 && pl.ko[1] == 1 && pl.ko[0] == pl.kshape[1] && x->dtype == md_dtype_of<Tacc>::value &&
+              (pl.kshape[1] % V) == 0 && (pl.rx[0] % V) == 0 && (pl.kx[0] % V) == 0 && ((uintptr_t)x->data & 15) == 0 && ((uintptr_t)out->data & 15) == 0 &&
+              pl.kshape[0] <= 65535 && pl.kshape[1] >= 256 && n_red >= 64) {
+            const int64_t outer = pl.kshape[0], inner = pl.kshape[1];
+            const int64_t NSb = ceil_div(inner, 64 * V);
+            int64_t NBb = NSb * outer >= MD_NUM_CUS ? 1 : MD_NUM_CUS / (NSb * outer);
+            if (NBb > 64) NBb = 64;
+            if (NBb > n_red / (4 * RB)) NBb = n_red / (4 * RB);
+            if (NBb < 1) NBb = 1;
+            if (NBb == 1 || NSb * outer * MD_TICKET_PAD <= MD_TICKET_WORDS) {
+              void *partial = nullptr;
+              if (NBb > 1) MD_TRY(mdhip_alloc((size_t)(outer * NBb * inner) * sizeof(Tacc), &partial));
+              const dim3 grid((unsigned)(NSb * NBb), (unsigned)outer);
+              MD_LAUNCH((k_reduce_cols_strips<R, Tacc, RB, false>), grid, MD_BLOCK, (const Tacc *)x->data, inner, n_red, pl.rx[0], (int)NSb, (int)NBb, (Tacc *)partial,
+                        md_tickets(), (Tacc *)out->data, (int64_t)pl.kx[0], (int64_t)inner);
+              int rc = MD_LAUNCH_CHECK("reduce(cols,strips,batched)");
+              if (partial) mdhip_free(partial);
+              return rc;
+            }
+          }
         }
         if (vec_ok) {
           const int64_t bxv = ceil_div(n_out, 64 * V);
