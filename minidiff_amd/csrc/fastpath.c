@@ -12,7 +12,8 @@
  *   FastOp      a callable per table entry: tries the C route, otherwise calls the Python implementation it wraps
  *
  * The C route takes: float32 / float64 device arrays that own valid memory (no pending lazy expression, no deferred fill),
- * optionally one weak Python scalar (int / float), any strides, NumPy broadcasting, eager mode. Everything else — other dtypes,
+ * optionally one weak Python scalar (int / float) or a bool array next to a float one, any strides, NumPy broadcasting, eager mode —
+ * for the elementwise entries, `where` (bool condition), 2-D `matmul`, and sum / prod / max / min of arrays below 2^18 elements. Everything else — other dtypes,
  * NumPy scalars, keyword arguments, lazy mode, storage-only dtypes, shape errors — goes to the Python implementation, which
  * also owns every error message: when the C route cannot serve a call, or the C-ABI returns a non-zero status, the call is
  * simply repeated there.
@@ -31,6 +32,8 @@ typedef int (*free_fn)(void *);
 typedef int (*unary_fn)(int, const mdhip_array *, const mdhip_array *);
 typedef int (*binary_fn)(int, const mdhip_array *, const mdhip_array *, const mdhip_array *, int);
 typedef int (*reduce_fn)(int, const mdhip_array *, const mdhip_array *, uint32_t);
+typedef int (*matmul_fn)(const mdhip_array *, const mdhip_array *, const mdhip_array *);
+typedef int (*where_fn)(const mdhip_array *, const mdhip_array *, const mdhip_array *, const mdhip_array *);
 
 static struct {
   alloc_fn alloc;
@@ -38,6 +41,8 @@ static struct {
   unary_fn unary;
   binary_fn binary;
   reduce_fn reduce;
+  matmul_fn matmul;
+  where_fn where;
   PyTypeObject *array_type;              /* ndarray.DeviceArray */
   PyObject *dtypes[MDHIP_NUM_DTYPES];    /* np.dtype by compute dtype code */
   PyObject *dtype_code;                  /* callable: np.dtype -> code (raises TypeError for an unsupported dtype) */
@@ -310,10 +315,10 @@ static inline int tuple_to_i64(PyObject *t, int64_t *out, int n) {
 }
 
 /* 1: usable operand; 0: not for the C route (no exception pending) */
-static int parse_operand(PyObject *x, Operand *o) {
+static int parse_operand_ex(PyObject *x, Operand *o, int allow_bool) {
   if (Py_TYPE(x) == G.array_type) {
     ArrayObject *a = (ArrayObject *)x;
-    if (a->code != MDHIP_F32 && a->code != MDHIP_F64) return 0;
+    if (a->code != MDHIP_F32 && a->code != MDHIP_F64 && !(allow_bool && a->code == MDHIP_BOOL)) return 0;
     if (!a->buf || Py_TYPE(a->buf) != &Buffer_Type) return 0;           /* pending, or a block of another owner type */
     BufferObject *b = (BufferObject *)a->buf;
     if ((b->task && b->task != Py_None) || !b->ptr) return 0;           /* deferred fill still owed */
@@ -355,6 +360,8 @@ static int parse_operand(PyObject *x, Operand *o) {
   }
   return 0;
 }
+
+static inline int parse_operand(PyObject *x, Operand *o) { return parse_operand_ex(x, o, 0); }
 
 static inline void array_desc(const Operand *o, mdhip_array *d) {
   const ArrayObject *a = o->arr;
@@ -490,15 +497,19 @@ static inline int needs_straighten(const Operand *o) {
 /* NULL without an exception: not served (repeat in Python) */
 static PyObject *binary_route(int op, PyObject *pa, PyObject *pb) {
   Operand a, b;
-  if (!parse_operand(pa, &a) || !parse_operand(pb, &b)) return NULL;
+  if (!parse_operand_ex(pa, &a, 1) || !parse_operand_ex(pb, &b, 1)) return NULL;
   if (!a.is_array && !b.is_array) return NULL;
   int cdt;
   if (a.is_array && b.is_array) {
-    if (a.code != b.code) return NULL;
-    cdt = a.code;
+    /* a bool array next to a float array computes in the float type (NumPy's loop for (f, ?): the grad * mask of a relu) */
+    if (a.code == MDHIP_BOOL && b.code != MDHIP_BOOL) cdt = b.code;
+    else if (b.code == MDHIP_BOOL && a.code != MDHIP_BOOL) cdt = a.code;
+    else if (a.code != b.code) return NULL;
+    else cdt = a.code;
   } else {
     cdt = a.is_array ? a.code : b.code;
   }
+  if (cdt == MDHIP_BOOL) return NULL;   /* bool with bool / with a Python scalar: NumPy's own rules, in Python */
   int odt = binary_out_code(op, cdt);
   if (odt < 0) return NULL;
   if (needs_straighten(&a) || needs_straighten(&b)) return NULL;
@@ -554,11 +565,164 @@ static PyObject *unary_route(int op, PyObject *px) {
   return (PyObject *)r;
 }
 
+/* a @ b for two 2-D float arrays of one dtype (the C-ABI takes (batch, rows, cols) descriptors) */
+static PyObject *matmul_route(PyObject *pa, PyObject *pb) {
+  Operand a, b;
+  if (!G.matmul || !parse_operand(pa, &a) || !parse_operand(pb, &b)) return NULL;
+  if (!a.is_array || !b.is_array || a.code != b.code || a.ndim != 2 || b.ndim != 2) return NULL;
+  const int64_t M = a.shape[0], K = a.shape[1], N = b.shape[1];
+  if (b.shape[0] != K || K == 0 || M == 0 || N == 0) return NULL;   /* (mismatch: NumPy's message; empty: a fill, both in Python) */
+  mdhip_array da, db, dc;
+  array_desc(&a, &da);
+  array_desc(&b, &db);
+  da.ndim = db.ndim = 3;
+  da.shape[0] = 1; da.shape[1] = M; da.shape[2] = K; da.strides[0] = 0; da.strides[1] = a.strides[0]; da.strides[2] = a.strides[1];
+  db.shape[0] = 1; db.shape[1] = K; db.shape[2] = N; db.strides[0] = 0; db.strides[1] = b.strides[0]; db.strides[2] = b.strides[1];
+  const int64_t shape[2] = {M, N};
+  ArrayObject *r = result_array(2, shape, a.code, NULL, NULL, &dc);
+  if (!r) {
+    PyErr_Clear();
+    return NULL;
+  }
+  dc.ndim = 3;
+  dc.shape[0] = 1; dc.shape[1] = M; dc.shape[2] = N; dc.strides[0] = M * N; dc.strides[1] = N; dc.strides[2] = 1;
+  if (G.matmul(&da, &db, &dc)) {
+    Py_DECREF(r);
+    return NULL;
+  }
+  return (PyObject *)r;
+}
+
+/* where(cond, x, y): cond a bool array; x, y float arrays of one dtype and / or weak Python scalars (at least one array) */
+static PyObject *where_route(PyObject *pc, PyObject *px, PyObject *py) {
+  Operand c, x, y;
+  if (!G.where || !parse_operand_ex(pc, &c, 1) || !parse_operand(px, &x) || !parse_operand(py, &y)) return NULL;
+  if (!c.is_array || c.code != MDHIP_BOOL) return NULL;
+  if (!x.is_array && !y.is_array) return NULL;          /* two Python scalars: NumPy's default dtypes, in Python */
+  if (x.is_array && y.is_array && x.code != y.code) return NULL;
+  const int odt = x.is_array ? x.code : y.code;
+  const Operand *arrs[3] = {&c, x.is_array ? &x : NULL, y.is_array ? &y : NULL};
+  int nd = 0;
+  for (int i = 0; i < 3; i++)
+    if (arrs[i] && arrs[i]->ndim > nd) nd = arrs[i]->ndim;
+  int64_t shape[MDHIP_MAX_NDIM];
+  for (int d = 1; d <= nd; d++) {
+    int64_t e = 1;
+    for (int i = 0; i < 3; i++) {
+      if (!arrs[i] || d > arrs[i]->ndim) continue;
+      const int64_t v = arrs[i]->shape[arrs[i]->ndim - d];
+      if (v == e || v == 1) continue;
+      if (e == 1) e = v;
+      else return NULL;   /* Python raises NumPy's broadcast error */
+    }
+    shape[nd - d] = e;
+  }
+  int64_t total = 1;
+  for (int i = 0; i < nd; i++) total *= shape[i];
+  if (total == 0) return NULL;
+  mdhip_array dcd, dx, dy, dr;
+  operand_desc(&c, nd, shape, &dcd);
+  operand_desc(&x, nd, shape, &dx);
+  operand_desc(&y, nd, shape, &dy);
+  ArrayObject *r = result_array(nd, shape, odt, x.is_array ? &x : &y, y.is_array ? &y : NULL, &dr);
+  if (!r) {
+    PyErr_Clear();
+    return NULL;
+  }
+  if (G.where(&dcd, &dx, &dy, &dr)) {
+    Py_DECREF(r);
+    return NULL;
+  }
+  return (PyObject *)r;
+}
+
+/* sum / prod / max / min of a SMALL float array (below the size at which Python re-expresses some forms through other kernels):
+ * args (x[, axis]), keywords axis / keepdims (dtype / out only as None) */
+#define MD_FAST_REDUCE_MAX (1 << 18)
+static int kw_is(PyObject *name, const char *s) { return PyUnicode_CompareWithASCIIString(name, s) == 0; }
+
+static PyObject *reduce_route(int op, PyObject *const *args, Py_ssize_t nargs, PyObject *kwnames) {
+  if (nargs < 1 || nargs > 2) return NULL;
+  PyObject *axis = nargs == 2 ? args[1] : Py_None;
+  int keepdims = 0;
+  const Py_ssize_t nkw = kwnames ? PyTuple_GET_SIZE(kwnames) : 0;
+  for (Py_ssize_t i = 0; i < nkw; i++) {
+    PyObject *name = PyTuple_GET_ITEM(kwnames, i), *v = args[nargs + i];
+    if (kw_is(name, "axis")) {
+      if (nargs == 2) return NULL;
+      axis = v;
+    } else if (kw_is(name, "keepdims")) {
+      if (v == Py_True) keepdims = 1;
+      else if (v != Py_False) return NULL;
+    } else if (kw_is(name, "dtype") || kw_is(name, "out")) {
+      if (v != Py_None) return NULL;
+    } else {
+      return NULL;
+    }
+  }
+  Operand x;
+  if (!parse_operand(args[0], &x) || !x.is_array || x.ndim == 0) return NULL;
+  int64_t total = 1;
+  for (int i = 0; i < x.ndim; i++) total *= x.shape[i];
+  if (total == 0 || total >= MD_FAST_REDUCE_MAX) return NULL;
+  uint32_t mask = 0;
+  if (axis == Py_None) {
+    mask = (1u << x.ndim) - 1u;
+  } else if (PyLong_CheckExact(axis)) {
+    long v = PyLong_AsLong(axis);
+    if (v == -1 && PyErr_Occurred()) { PyErr_Clear(); return NULL; }
+    if (v < -x.ndim || v >= x.ndim) return NULL;
+    mask = 1u << (v < 0 ? v + x.ndim : v);
+  } else if (PyTuple_CheckExact(axis)) {
+    for (Py_ssize_t i = 0; i < PyTuple_GET_SIZE(axis); i++) {
+      PyObject *e = PyTuple_GET_ITEM(axis, i);
+      if (!PyLong_CheckExact(e)) return NULL;
+      long v = PyLong_AsLong(e);
+      if (v == -1 && PyErr_Occurred()) { PyErr_Clear(); return NULL; }
+      if (v < -x.ndim || v >= x.ndim) return NULL;
+      const uint32_t bit = 1u << (v < 0 ? v + x.ndim : v);
+      if (mask & bit) return NULL;   /* duplicate: NumPy's ValueError, in Python */
+      mask |= bit;
+    }
+  } else {
+    return NULL;
+  }
+  /* the kernel writes the kept-dims form; the returned array has the reduced axes dropped unless keepdims */
+  int64_t kshape[MDHIP_MAX_NDIM], fshape[MDHIP_MAX_NDIM];
+  int fnd = 0;
+  for (int i = 0; i < x.ndim; i++) {
+    const int red = (mask >> i) & 1u;
+    kshape[i] = red ? 1 : x.shape[i];
+    if (keepdims || !red) fshape[fnd++] = kshape[i];
+  }
+  mdhip_array dx, dr;
+  array_desc(&x, &dx);
+  ArrayObject *r = result_array(fnd, fshape, x.code, NULL, NULL, &dr);
+  if (!r) {
+    PyErr_Clear();
+    return NULL;
+  }
+  dr.ndim = x.ndim;
+  int64_t acc = 1;
+  for (int i = x.ndim - 1; i >= 0; i--) {
+    dr.shape[i] = kshape[i];
+    dr.strides[i] = acc;
+    acc *= kshape[i];
+  }
+  if (G.reduce(op, &dx, &dr, mask)) {
+    Py_DECREF(r);
+    return NULL;
+  }
+  return (PyObject *)r;
+}
+
 /* =========================================================================== FastOp */
+enum { KIND_UNARY = 1, KIND_BINARY = 2, KIND_MATMUL = 3, KIND_WHERE = 4, KIND_REDUCE = 5 };
+
 typedef struct {
   PyObject_HEAD
   vectorcallfunc vectorcall;
-  int arity; /* 1 / 2 */
+  int kind; /* KIND_* */
   int code;
   PyObject *slow; /* the Python implementation */
   PyObject *name;
@@ -567,8 +731,18 @@ typedef struct {
 
 static PyObject *FastOp_vectorcall(PyObject *self_, PyObject *const *args, size_t nargsf, PyObject *kwnames) {
   FastOpObject *self = (FastOpObject *)self_;
-  if (G.ops_enabled && !G.lazy && PyVectorcall_NARGS(nargsf) == self->arity && (!kwnames || PyTuple_GET_SIZE(kwnames) == 0)) {
-    PyObject *r = self->arity == 2 ? binary_route(self->code, args[0], args[1]) : unary_route(self->code, args[0]);
+  if (G.ops_enabled && !G.lazy) {
+    const Py_ssize_t n = PyVectorcall_NARGS(nargsf);
+    const int nokw = !kwnames || PyTuple_GET_SIZE(kwnames) == 0;
+    PyObject *r = NULL;
+    switch (self->kind) {
+      case KIND_UNARY: if (n == 1 && nokw) r = unary_route(self->code, args[0]); break;
+      case KIND_BINARY: if (n == 2 && nokw) r = binary_route(self->code, args[0], args[1]); break;
+      case KIND_MATMUL: if (n == 2 && nokw) r = matmul_route(args[0], args[1]); break;
+      case KIND_WHERE: if (n == 3 && nokw) r = where_route(args[0], args[1], args[2]); break;
+      case KIND_REDUCE: r = reduce_route(self->code, args, n, kwnames); break;
+      default: break;
+    }
     if (r) {
       G.served++;
       return r;
@@ -580,17 +754,17 @@ static PyObject *FastOp_vectorcall(PyObject *self_, PyObject *const *args, size_
 }
 
 static PyObject *FastOp_new(PyTypeObject *type, PyObject *args, PyObject *kw) {
-  int arity, code;
+  int kind, code;
   PyObject *slow, *name;
-  if (!PyArg_ParseTuple(args, "iiOU", &arity, &code, &slow, &name)) return NULL;
-  if ((arity != 1 && arity != 2) || !PyCallable_Check(slow)) {
-    PyErr_SetString(PyExc_TypeError, "FastOp(arity in (1, 2), code, callable, name)");
+  if (!PyArg_ParseTuple(args, "iiOU", &kind, &code, &slow, &name)) return NULL;
+  if (kind < KIND_UNARY || kind > KIND_REDUCE || !PyCallable_Check(slow)) {
+    PyErr_SetString(PyExc_TypeError, "FastOp(kind: 1 unary / 2 binary / 3 matmul / 4 where / 5 reduce, code, callable, name)");
     return NULL;
   }
   FastOpObject *f = (FastOpObject *)type->tp_alloc(type, 0);
   if (!f) return NULL;
   f->vectorcall = FastOp_vectorcall;
-  f->arity = arity;
+  f->kind = kind;
   f->code = code;
   Py_INCREF(slow);
   f->slow = slow;
@@ -636,7 +810,7 @@ static PyTypeObject FastOp_Type = {
     .tp_repr = (reprfunc)FastOp_repr,
     .tp_call = PyVectorcall_Call,
     .tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_HAVE_GC | Py_TPFLAGS_HAVE_VECTORCALL,
-    .tp_doc = "FastOp(arity, code, python_implementation, name): one table entry with the C route in front.",
+    .tp_doc = "FastOp(kind, code, python_implementation, name): one table entry with the C route in front.",
     .tp_traverse = (traverseproc)FastOp_traverse,
     .tp_clear = (inquiry)FastOp_clear,
     .tp_members = FastOp_members,
@@ -714,9 +888,9 @@ static PyObject *fp_bind(PyObject *mod, PyObject *d) {
     return NULL;
   }
   unsigned long long a = addr_of(d, "mdhip_alloc"), f = addr_of(d, "mdhip_free"), u = addr_of(d, "mdhip_unary"), b = addr_of(d, "mdhip_binary"),
-                     r = addr_of(d, "mdhip_reduce");
+                     r = addr_of(d, "mdhip_reduce"), mm = addr_of(d, "mdhip_matmul"), wh = addr_of(d, "mdhip_where");
   if (PyErr_Occurred()) return NULL;
-  if (!a || !f || !u || !b || !r) {
+  if (!a || !f || !u || !b || !r || !mm || !wh) {
     PyErr_SetString(PyExc_ValueError, "bind: null entry point");
     return NULL;
   }
@@ -725,6 +899,8 @@ static PyObject *fp_bind(PyObject *mod, PyObject *d) {
   G.unary = (unary_fn)(uintptr_t)u;
   G.binary = (binary_fn)(uintptr_t)b;
   G.reduce = (reduce_fn)(uintptr_t)r;
+  G.matmul = (matmul_fn)(uintptr_t)mm;
+  G.where = (where_fn)(uintptr_t)wh;
   Py_RETURN_NONE;
 }
 

@@ -2656,7 +2656,8 @@ def _install_fastpath(ns):
     _fp.set_lazy(_LAZY)
 
     def bind(lib):
-        _fp.bind({name: _capi.entry_address(lib, name) for name in ("mdhip_alloc", "mdhip_free", "mdhip_unary", "mdhip_binary", "mdhip_reduce")})
+        _fp.bind({name: _capi.entry_address(lib, name) for name in ("mdhip_alloc", "mdhip_free", "mdhip_unary", "mdhip_binary", "mdhip_reduce", "mdhip_matmul",
+                                                                     "mdhip_where")})
         _fp.enable_ops(True)
 
     _capi._BIND_HOOKS.append(bind)
@@ -2673,6 +2674,10 @@ def _install_fastpath(ns):
         ns[name] = _fp.FastOp(1, code, ns[name], name)
     for name, code in binary.items():
         ns[name] = _fp.FastOp(2, code, ns[name], name)
+    ns["matmul"] = _fp.FastOp(3, 0, ns["matmul"], "matmul")
+    ns["where"] = _fp.FastOp(4, 0, ns["where"], "where")
+    for name, code in (("sum", _capi.R_SUM), ("prod", _capi.R_PROD), ("max", _capi.R_MAX), ("min", _capi.R_MIN)):
+        ns[name] = _fp.FastOp(5, code, ns[name], name)
 
 
 _install_fastpath(globals())

@@ -115,6 +115,97 @@ def test_calls_the_c_route_hands_to_python(eager):
         nd.add(f)
 
 
+def test_matmul_where_reduce_and_bool_partner_routes(eager):
+    rng = np.random.default_rng(9)
+    for dtype in (np.float32, np.float64):
+        a = rng.integers(-3, 4, (24, 16)).astype(dtype)
+        b = rng.integers(-3, 4, (16, 40)).astype(dtype)
+        A, B = nd.asarray(a), nd.asarray(b)
+        At, Bt = nd.asarray(np.ascontiguousarray(a.T)), nd.asarray(np.ascontiguousarray(b.T))
+        for x, y in ((A, B), (At.T, B), (A, Bt.T), (At.T, Bt.T), (A[::2], B[:, ::2])):
+            got, served, passed = _served(nd.matmul, x, y)
+            assert (served, passed) == (1, 0)
+            _same(got, nd.matmul.__wrapped__(x, y))
+            assert np.array_equal(got.get(), x.get().astype(np.float64) @ y.get())
+        # where: bool condition, array / scalar branches, broadcasting
+        c = nd.asarray(rng.random((24, 16)) < 0.5)
+        row = nd.asarray(rng.standard_normal((16,)).astype(dtype))
+        for x, y in ((A, 0), (0.5, A), (A, nd.multiply(A, 2.0)), (A, row), (row, A)):
+            got, served, passed = _served(nd.where, c, x, y)
+            assert (served, passed) == (1, 0)
+            _same(got, nd.where.__wrapped__(c, x, y))
+            hx = x.get() if isinstance(x, nd.DeviceArray) else x
+            hy = y.get() if isinstance(y, nd.DeviceArray) else y
+            exp = np.where(c.get(), hx, hy)
+            assert got.dtype == exp.dtype and np.array_equal(got.get(), exp)
+        got, served, _ = _served(nd.where, nd.asarray(np.array([True, False] * 8)), A, 1)     # a condition row broadcast over A
+        assert served == 1 and np.array_equal(got.get(), np.where(np.array([True, False] * 8), a, 1))
+        # a bool array next to a float one: the float loop
+        m = nd.asarray(rng.random((24, 16)) < 0.5)
+        for name in ("multiply", "add", "subtract", "true_divide", "maximum", "greater", "equal"):
+            fn = getattr(nd, name)
+            with np.errstate(all="ignore"):
+                for x, y in ((A, m), (m, A)):
+                    got, served, passed = _served(fn, x, y)
+                    assert (served, passed) == (1, 0), name
+                    _same(got, fn.__wrapped__(x, y))
+                    exp = getattr(np, name)(x.get(), y.get())
+                    assert got.dtype == exp.dtype
+        # reductions of small arrays
+        t = nd.asarray(rng.integers(-3, 4, (6, 5, 8)).astype(dtype))
+        for name in ("sum", "prod", "max", "min"):
+            fn = getattr(nd, name)
+            forms = [((t,), {}), ((t,), {"axis": None}), ((t,), {"axis": 1}), ((t, 2), {}), ((t,), {"axis": (0, 2), "keepdims": True}),
+                     ((t,), {"axis": -1, "keepdims": False, "dtype": None}), ((t,), {"axis": (2, 0, 1)}), ((t[:, ::2],), {"axis": (1,)}),
+                     ((nd.transpose(t),), {"axis": 0})]
+            for args, kw in forms:
+                if "dtype" in kw and name in ("max", "min"):
+                    continue                                 # (np.max takes no dtype)
+                before = fp.stats()
+                got = fn(*args, **kw)
+                after = fp.stats()
+                assert after["served"] - before["served"] == 1, (name, kw)
+                _same(got, fn.__wrapped__(*args, **kw))
+                hargs = [x.get() if isinstance(x, nd.DeviceArray) else x for x in args]
+                exp = getattr(np, name)(*hargs, **kw)
+                assert got.shape == exp.shape and got.dtype == exp.dtype
+                np.testing.assert_allclose(got.get(), exp, rtol=1e-5)
+        assert t.sum(axis=1).shape == (6, 8)            # the method spelling passes dtype=None / keepdims by keyword
+
+
+def test_forms_the_new_routes_leave_to_python(eager):
+    f = nd.asarray(np.arange(24, dtype=np.float32).reshape(4, 6))
+    g = nd.asarray(np.arange(24, dtype=np.float64).reshape(6, 4))
+    i = nd.asarray(np.arange(24, dtype=np.int32).reshape(6, 4))
+    v = nd.asarray(np.arange(6, dtype=np.float32))
+    b = nd.asarray(np.ones((4, 6), dtype=np.bool_))
+    passed_cases = [
+        (nd.matmul, (f, v), {}), (nd.matmul, (f, g), {}), (nd.matmul, (f, i), {}),            # a vector, mixed widths, integers
+        (nd.matmul, (nd.asarray(np.ones((2, 4, 6), dtype=np.float32)), nd.asarray(np.ones((6, 3), dtype=np.float32))), {}),   # batched
+        (nd.where, (b, 1, 2), {}), (nd.where, (b, f, np.float32(1)), {}), (nd.where, (f, f, 0), {}),   # two scalars, a NumPy scalar, a float condition
+        (nd.sum, (f,), {"dtype": np.float64}), (nd.sum, (i,), {}), (nd.sum, (f,), {"axis": np.int64(0)}),
+        (nd.sum, (nd.asarray(np.ones((1 << 9, 1 << 9), dtype=np.float32)),), {}),             # 2^18 elements: Python's staging rules apply
+        (nd.multiply, (b, b), {}), (nd.multiply, (b, 2.0), {}),
+    ]
+    for fn, args, kw in passed_cases:
+        before = fp.stats()
+        got = fn(*args, **kw)
+        after = fp.stats()
+        assert after["served"] == before["served"] and after["passed"] - before["passed"] >= 1, (fn, kw)
+        hargs = [x.get() if isinstance(x, nd.DeviceArray) else x for x in args]
+        exp = getattr(np, fn.__name__)(*hargs, **kw)
+        assert got.dtype == exp.dtype and got.shape == exp.shape
+        np.testing.assert_allclose(got.get(), exp, rtol=1e-6)
+    with pytest.raises(ValueError, match="mismatch in its core dimension"):
+        nd.matmul(f, f)
+    with pytest.raises(ValueError, match="duplicate"):
+        nd.sum(f, axis=(0, 0))
+    with pytest.raises(np.exceptions.AxisError):
+        nd.sum(f, axis=2)
+    with pytest.raises(ValueError, match="could not be broadcast"):
+        nd.where(b, f, v[:5])
+
+
 def test_lazy_mode_bypasses_the_c_route(lib):
     a = nd.asarray(np.arange(8, dtype=np.float32))
     prev = nd.set_lazy(True)
