@@ -36,7 +36,15 @@ from ._capi import ArrayDesc, IndexPlan, MAX_NDIM
 # MDHIP_FASTPATH=0 (A/B of the host cost, scripts/host_overhead.py) and under MDHIP_TRACE (the call log sits in the ctypes layer).
 if os.environ.get("MDHIP_FASTPATH", "1") != "0" and not os.environ.get("MDHIP_TRACE"):
     try:
-        from . import _fastpath as _fp
+        if os.environ.get("MDHIP_FASTPATH_SO"):   # TESTS ONLY: a named build of the extension (the sanitizer build, tests/test_sanitized_double.py)
+            import importlib.util
+            import sys as _sys
+            _spec = importlib.util.spec_from_file_location(__package__ + "._fastpath", os.environ["MDHIP_FASTPATH_SO"])
+            _fp = importlib.util.module_from_spec(_spec)
+            _spec.loader.exec_module(_fp)
+            _sys.modules[__package__ + "._fastpath"] = _fp
+        else:
+            from . import _fastpath as _fp
     except ImportError as e:  # built by `make -C minidiff_amd/csrc` next to libmdhip.so; host-only C, one gcc call: build it now
         import subprocess
         import sysconfig
