@@ -54,6 +54,36 @@ __global__ void __launch_bounds__(MD_BLOCK) k_gather_vec(mdhip_index_plan pl, in
   }
 }
 
+// LONG runs (rows of >= 64 units: an embedding lookup W[idx], a[idx] selecting whole rows of a wide matrix): the plan arithmetic of
+// a run — the div / mod chain over the plan's axes and the index loads — is done ONCE per run by the wave that copies it, and the
+// run itself moves as coalesced 16-B units, four in flight per lane. k_gather_vec above pays that arithmetic per 16-B unit
+// (8192 rows x 16 KiB: 79 us; a plain copy of the same bytes takes 48).
+__global__ void __launch_bounds__(MD_BLOCK) k_gather_runs(mdhip_index_plan pl, int64_t n_runs, int64_t run_elems, int vshift, const uint4 *__restrict__ src,
+                                                         uint4 *__restrict__ out, MdIter oit, int *err) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t lu = run_elems >> vshift;   // units per run
+  for (int64_t p = wave; p < n_runs; p += n_waves) {
+    int64_t pos[MDHIP_MAX_NDIM];
+    bool oob = false;
+    const int64_t off = md_plan_offset(pl, p * run_elems, pos, &oob);   // (the same for every lane of the wave)
+    if (oob) {
+      if (lane == 0) *err = 1;
+      continue;
+    }
+    int64_t oo = 0;
+    for (int d = 0; d < pl.ndim; ++d) oo += pos[d] * oit.strides[0][d];
+    const uint4 *s = src + (off >> vshift);
+    uint4 *o = out + (oo >> vshift);
+    int64_t u = lane;
+    for (; u + 192 < lu; u += 256) {
+      const uint4 a = s[u], b = s[u + 64], c = s[u + 128], d = s[u + 192];
+      o[u] = a; o[u + 64] = b; o[u + 128] = c; o[u + 192] = d;
+    }
+    for (; u < lu; u += 64) o[u] = s[u];
+  }
+}
+
 // `step` > 1: only every step-th position is probed (run plans: no index varies along the last axis)
 __global__ void __launch_bounds__(MD_BLOCK) k_check_bounds(mdhip_index_plan pl, int64_t count, int64_t step, int *err) {
   const int64_t gs = (int64_t)gridDim.x * blockDim.x;
@@ -656,7 +686,16 @@ int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const m
   }
   if (runs) {
     const int vshift = V == 16 ? 4 : V == 4 ? 2 : 1;
-    k_gather_vec<<<md_grid_for(total / V), MD_BLOCK, 0, st>>>(*pl, total / V, vshift, (const uint4 *)src, (uint4 *)out->data, oit, (int *)flag);
+    const int64_t run_elems = pl->shape[nd - 1], n_runs = total / run_elems;
+    static const bool runs_on = [] { const char *e = getenv("MDHIP_GATHER_RUNS"); return !(e && e[0] == '0'); }();   // 0: per-unit plan arithmetic (A/B)
+    if (runs_on && run_elems / V >= 64 && n_runs >= 64) {
+      // a wave per run, up to 16 waves per CU resident (64 KiB of loads in flight per CU)
+      int64_t blocks = (n_runs + 3) / 4;
+      if (blocks > 1024) blocks = 1024;
+      k_gather_runs<<<(unsigned)blocks, MD_BLOCK, 0, st>>>(*pl, n_runs, run_elems, vshift, (const uint4 *)src, (uint4 *)out->data, oit, (int *)flag);
+    } else {
+      k_gather_vec<<<md_grid_for(total / V), MD_BLOCK, 0, st>>>(*pl, total / V, vshift, (const uint4 *)src, (uint4 *)out->data, oit, (int *)flag);
+    }
   } else
   switch (md_dtype_size(dtype)) {
     case 1: k_gather<uint8_t><<<grid, MD_BLOCK, 0, st>>>(*pl, total, (const uint8_t *)src, (uint8_t *)out->data, oit, (int *)flag); break;
