@@ -310,6 +310,8 @@ extern "C" int mdhip_var(const mdhip_array *x, const mdhip_array *out, int32_t a
   const double denom = (double)(n - ddof);
   if (inner == 1) {
     if (n % V) return md_fail(MDHIP_EVALUE, "var: row length not a multiple of the 16-B vector");
+    // a row is one wave's / one block's work: a few very long rows would leave the chip idle (the composed passes use all of it)
+    if (outer < 256 && n > 16384) return md_fail(MDHIP_EVALUE, "var: few long rows (the caller composes)");
     return x->dtype == MDHIP_F32 ? var_rows<float>((const float *)x->data, outer, n, (float *)out->data, (float)denom, take_sqrt)
                                  : var_rows<double>((const double *)x->data, outer, n, (double *)out->data, denom, take_sqrt);
   }

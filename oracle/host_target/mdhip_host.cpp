@@ -346,6 +346,8 @@ int mdhip_var(const mdhip_array *x, const mdhip_array *out, int32_t axis, int64_
   if (((uintptr_t)x->data & 15) || ((uintptr_t)out->data & 15)) return md_fail(MDHIP_EVALUE, "var: unaligned operands");
   if (inner == 1) {
     if (n % V) return md_fail(MDHIP_EVALUE, "var: row length not a multiple of the 16-B vector");
+    // a row is one wave's / one block's work: a few very long rows would leave the chip idle (the composed passes use all of it)
+    if (outer < 256 && n > 16384) return md_fail(MDHIP_EVALUE, "var: few long rows (the caller composes)");
   } else if (outer == 1) {
     if ((inner % V) || n < 64 || inner < 256) return md_fail(MDHIP_EVALUE, "var: column form needs >= 256 aligned columns and >= 64 rows");
   } else {

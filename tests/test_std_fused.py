@@ -17,7 +17,7 @@ def test_rows_and_columns_take_the_kernel_and_match_numpy(lib, dtype):
     rng = np.random.default_rng(57)
     prev = nd.set_lazy(False)
     try:
-        shapes_axes = [((7, 8), 1), ((5, 3, 64), 2), ((33, 2048), -1), ((9, 2052), 1), ((3, 5000), 1), ((2, 20000), 1), ((4, 70000), -1),
+        shapes_axes = [((7, 8), 1), ((5, 3, 64), 2), ((33, 2048), -1), ((9, 2052), 1), ((3, 5000), 1), ((300, 20000), 1), ((256, 70000), -1),
                        ((64, 256), 0), ((1000, 512), 0), ((129, 260), 0), ((4096,), 0), ((4096,), None)]
         for shape, axis in shapes_axes:
             h = (rng.standard_normal(shape) * 3 + 10).astype(dtype)          # a mean well away from 0: E[x^2] - mean^2 would lose digits
@@ -50,6 +50,7 @@ def test_other_forms_are_composed_as_before(lib):
             (d, 2, np.float64, 0),                                          # a different accumulation dtype
             (nd.asarray(h[0, :, :4].copy()), 0, None, 0),                   # a narrow, short column form
             (d, 2, None, 12), (d, 2, None, 13),                             # degenerate counts: NumPy's inf / nan
+            (nd.asarray(rng.standard_normal((2, 20000)).astype(np.float32)), 1, None, 0),   # two long rows: one block each would idle the chip
         ]
         with np.errstate(all="ignore"):
             for arr, axis, dt, ddof in cases:
