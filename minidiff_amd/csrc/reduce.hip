@@ -970,12 +970,13 @@ struct HipExec {
         static const bool strips_on = [] { const char *e = getenv("MDHIP_ARG_STRIPS"); return !(e && e[0] == '0'); }();   // 0: the chunked kernel + finish pass (A/B)
         if (strips_on && n_red < (1ll << 31) && n_red >= 64 && bxv * MD_TICKET_PAD <= MD_TICKET_WORDS) {
           const int64_t NS = bxv;
-          int64_t NB = ceil_div(1024, NS);
+          static const int arg_blocks = [] { const char *e = getenv("MDHIP_ARG_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : MD_NUM_CUS; }();   // one block per CU, as the column sums (rocprofv3: 26.6 us against 38.0 with four per CU); the knob is for experiments
+          int64_t NB = ceil_div(arg_blocks, NS);
           if (NB > 64) NB = 64;
           if (NB > n_red / 32) NB = n_red / 32;
           if (NB < 1) NB = 1;
           while (NB > 1 && NB * n_out * 8 >= (1ll << 31)) NB /= 2;   // (32-bit byte offsets into the partial rows)
-          constexpr int ARG_RB = 4;   // (8 rows per batch: 135-141 registers, three waves per SIMD; 4: four waves)
+          constexpr int ARG_RB = 4;   // (rocprofv3 at one block per CU: 26.6 us with 4 rows per batch, 28.4 with 8)
           void *pv = nullptr, *pi = nullptr;
           if (NB > 1) {
             MD_TRY(mdhip_alloc((size_t)(NB * n_out) * sizeof(T), &pv));
