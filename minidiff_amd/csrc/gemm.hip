@@ -924,17 +924,30 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_f32_kc_glds(GemmArgs g) {
     md_epi_bias_relu<BM, BN, WM, WN, NPASS>(acc, g, m0, n0, reinterpret_cast<uint32_t *>(A0), B0);
     return;
   }
-  if constexpr (CT) {   // C^T addressing of a swapped TT product: rows are the unit-stride axis
+  if constexpr (CT) {
+    // C^T addressing of a swapped TT product: rows are the unit-stride axis. A lane holds four consecutive rows of ONE column, so
+    // stored as they stand a wave-store is 32 columns x 32 B — pieces of lines, which drain slowly (the kernel lasted 1041 us against
+    // NN's 942 with dispatches serialised). Each 32 x 32 accumulator tile is transposed through a wave-private LDS patch instead
+    // ([column][row], rows padded to 36 words: 16-B aligned, conflict-light) and leaves as whole 128-B row segments: eight lanes per
+    // C^T row, eight rows per store.
+    __shared__ __attribute__((aligned(16))) float Tt[WM * WN][32][36];
+    float(*T)[36] = Tt[wave];
+    const int rl = lane >> 3, cl = (lane & 7) * 4;   // read side: column rl + 8k of the tile, rows cl .. cl + 3
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
       for (int j = 0; j < WTN; ++j) {
-        const int64_t col = n0 + wn * (WTN * 32) + j * 32 + l32;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int64_t row = m0 + wm * (WTM * 32) + i * 32 + 8 * q + 4 * h;
-          *reinterpret_cast<f32x4 *>(C + row + col * g.c_ns) = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4 *>(&T[l32][8 * q + 4 * h]) = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        __builtin_amdgcn_wave_barrier();   // (the LDS queue of a wave is in order: the reads below see the writes above)
+        const int64_t row = m0 + wm * (WTM * 32) + i * 32 + cl;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int64_t col = n0 + wn * (WTN * 32) + j * 32 + rl + 8 * k;
+          *reinterpret_cast<f32x4 *>(C + row + col * g.c_ns) = *reinterpret_cast<const f32x4 *>(&T[rl + 8 * k][cl]);
         }
+        __builtin_amdgcn_wave_barrier();
       }
     return;
   }
