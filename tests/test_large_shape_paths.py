@@ -318,6 +318,38 @@ def test_thin_products_streaming_kernels_gpu(lib, on_gpu):
         got = nd.matmul(x, nd.asarray(v)).get()
         assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
 
+@gpu
+def test_any_all_of_whole_arrays_gpu(lib, on_gpu):
+    """any / all over a whole contiguous array (reduce.hip, k_anyall_flat): truth values from 16-B vectors of the array's own type.
+    One true among zeros / one zero among ones at the first, a middle, the last vector and in the scalar tail; NaN is true, -0.0 is
+    false; every dtype; sizes that are not whole vectors; several axes of an N-d array."""
+    assert on_gpu
+    rng = np.random.default_rng(99)
+    for dtype in (np.bool_, np.int32, np.int64, np.float32, np.float64):
+        for n in (1 << 16, (1 << 20) + 7, 3_000_001):
+            for pos in (0, n // 2 + 3, n - 17, n - 1):
+                h = np.zeros(n, dtype=dtype)
+                assert not bool(nd.any(nd.asarray(h)).item()) and not bool(nd.all(nd.asarray(h)).item())
+                h[pos] = 1
+                assert bool(nd.any(nd.asarray(h)).item()) and not bool(nd.all(nd.asarray(h)).item()), (dtype, n, pos)
+                h = np.ones(n, dtype=dtype)
+                assert bool(nd.all(nd.asarray(h)).item()) and bool(nd.any(nd.asarray(h)).item())
+                h[pos] = 0
+                assert not bool(nd.all(nd.asarray(h)).item()) and bool(nd.any(nd.asarray(h)).item()), (dtype, n, pos)
+    f = np.zeros(1 << 17, dtype=np.float32)
+    f[12345] = -0.0
+    assert not bool(nd.any(nd.asarray(f)).item())
+    f[54321] = np.nan
+    assert bool(nd.any(nd.asarray(f)).item())
+    g = np.full(1 << 17, np.nan, dtype=np.float64)
+    assert bool(nd.all(nd.asarray(g)).item())
+    t = rng.standard_normal((64, 33, 129)).astype(np.float32)
+    d = nd.asarray(t)
+    assert bool(nd.any(nd.isnan(d)).item()) is False and bool(nd.all(nd.less(d, 100.0)).item()) is True
+    t[63, 32, 128] = np.nan
+    assert bool(nd.any(nd.isnan(nd.asarray(t))).item()) is True
+    assert np.array_equal(nd.any(nd.asarray(t > 3), axis=(0, 1, 2), keepdims=True).get(), np.any(t > 3, axis=(0, 1, 2), keepdims=True))
+
 
 def test_ragged_matmul_cpu(lib, on_gpu):
     if on_gpu:
