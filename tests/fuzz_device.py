@@ -195,6 +195,12 @@ def one_case(rng, big):
                 # blocks in NumPy): ~sqrt(n) ulp typically — 1e6 factors once missed a flat 50-ulp bound (seed 101 --big)
                 n_red = max(h.size // max(exp.size, 1), 1)
                 slack = 50 * max(1.0, (n_red / 4096.0) ** 0.5) if name == "prod" else 1
+                if name == "prod":
+                    # .. and when many factors are IDENTICAL (a saturated tanh makes them all 1.001) the two halves of a tree node
+                    # carry the same rounding error, which then doubles per level instead of random-walking: the a-priori bound
+                    # (n - 1) u is attained in order of magnitude (3e-4 on 33,410 float32 factors, seed 71 --big case 3138); NumPy's
+                    # sequential product does not meet that case. The bound below is that a-priori bound, n * eps.
+                    slack = max(slack, n_red * float(np.finfo(h.dtype).eps) / tol)
                 fin = np.isfinite(exp)    # (a product of 1e6 factors may overflow on both sides: non-finite entries must simply agree)
                 assert np.array_equal(got[~fin], exp[~fin], equal_nan=True), f"{name} {h.shape}{h.dtype} axis={axis}: non-finite entries differ"
                 if not fin.all():
