@@ -95,6 +95,19 @@ __global__ void __launch_bounds__(MD_BLOCK) k_check_bounds(mdhip_index_plan pl, 
   }
 }
 
+// Run plans (whole rows): the bounds probe and a census of the destination rows in one pass — a row hit twice sets bit 1 of the
+// flag. Unique rows (a permutation, distinct token ids) need no ordering at all: the sort of scatter_runs is skipped for them.
+__global__ void __launch_bounds__(MD_BLOCK) k_check_bounds_dups(mdhip_index_plan pl, int64_t P, int64_t L, int64_t lo, int64_t unit, int *cnt, int *flag) {
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gs) {
+    int64_t pos[MDHIP_MAX_NDIM];
+    bool oob = false;
+    const int64_t off = md_plan_offset(pl, p * L, pos, &oob);
+    if (oob) { atomicOr(flag, 1); continue; }
+    if (atomicAdd(cnt + (off - lo) / unit, 1) > 0) atomicOr(flag, 2);
+  }
+}
+
 struct ValDesc {
   const void *p;
   int is_scalar;
@@ -464,10 +477,8 @@ static int radix_sort_pairs(uint64_t *keys, int64_t *ids, int64_t P, int key_bit
   return rc;
 }
 
-template <class T, int MODE>
-static int scatter_runs(const mdhip_index_plan *pl, int64_t P, int64_t L, void *dst, const ValDesc &v, T s) {
-  hipStream_t st = md_stream();
-  // key range from the plan (host side): offsets lie in [lo, hi]; keys are offset - lo, so the sort needs bits(hi - lo) only
+// key range of a run plan (host side): row offsets lie in [lo, hi]
+static void run_key_range(const mdhip_index_plan *pl, int64_t L, int64_t *lo_out, int64_t *hi_out) {
   int64_t lo = 0, hi = L - 1;
   for (int d = 0; d < pl->ndim - 1; ++d) {
     const int64_t e = (pl->shape[d] - 1) * pl->src_strides[d];
@@ -477,6 +488,17 @@ static int scatter_runs(const mdhip_index_plan *pl, int64_t P, int64_t L, void *
     const int64_t e = (pl->idx_extent[k] - 1) * pl->idx_mult[k];
     if (e < 0) lo += e; else hi += e;
   }
+  *lo_out = lo;
+  *hi_out = hi;
+}
+
+// `unique`: the census of the bounds pass found no destination row twice — plan order is irrelevant, no sort
+template <class T, int MODE>
+static int scatter_runs(const mdhip_index_plan *pl, int64_t P, int64_t L, void *dst, const ValDesc &v, T s, bool unique) {
+  hipStream_t st = md_stream();
+  // keys are offset - lo, so the sort needs bits(hi - lo) only
+  int64_t lo, hi;
+  run_key_range(pl, L, &lo, &hi);
   int64_t L2 = 0, P2 = 0, unit = 1;
   run_geometry(pl, &L2, &P2, &unit);
   int key_bits = 1;
@@ -489,7 +511,7 @@ static int scatter_runs(const mdhip_index_plan *pl, int64_t P, int64_t L, void *
     int64_t *iin = (int64_t *)ids;
     k_run_offsets<<<md_grid_for(P), MD_BLOCK, 0, st>>>(*pl, P, L, lo, unit, kin, iin);
     int half = 0;
-    rc = radix_sort_pairs(kin, iin, P, key_bits, &half);
+    if (!unique) rc = radix_sort_pairs(kin, iin, P, key_bits, &half);   // (unique rows: the apply kernels only ever look at EQUAL neighbouring keys)
     if (rc == MDHIP_OK) {
       const uint64_t *kout = kin + half * P;
       const int64_t *iout = iin + half * P;
@@ -535,7 +557,7 @@ static int scatter_ordered(const mdhip_index_plan *pl, int64_t total, void *dst,
 }
 
 template <class T>
-static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, const mdhip_array *val, int mode) {
+static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, const mdhip_array *val, int mode, bool unique_rows) {
   hipStream_t st = md_stream();
   ValDesc v;
   v.p = val->data;
@@ -551,7 +573,7 @@ static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, c
   int64_t L = 0, P = 0;
   const bool runs = run_geometry(pl, &L, &P);
   if (mode == MDHIP_SCATTER_SET) {
-    if (runs) return scatter_runs<T, MDHIP_SCATTER_SET>(pl, P, L, dst, v, s);
+    if (runs) return scatter_runs<T, MDHIP_SCATTER_SET>(pl, P, L, dst, v, s, unique_rows);
     return scatter_ordered<T, MDHIP_SCATTER_SET>(pl, total, dst, v, s);
   }
   if constexpr (md_same<T, uint8_t>::value) {
@@ -561,7 +583,7 @@ static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, c
     k_scatter_add_int<T><<<md_grid_for(total), MD_BLOCK, 0, st>>>(*pl, total, (T *)dst, v, s);
     return MD_LAUNCH_CHECK("scatter(add,int)");
   } else {
-    if (runs) return scatter_runs<T, MDHIP_SCATTER_ADD>(pl, P, L, dst, v, s);
+    if (runs) return scatter_runs<T, MDHIP_SCATTER_ADD>(pl, P, L, dst, v, s, unique_rows);
     return scatter_ordered<T, MDHIP_SCATTER_ADD>(pl, total, dst, v, s);
   }
 }
@@ -739,22 +761,38 @@ int mdhip_scatter(const mdhip_index_plan *pl, void *dst, int dtype, const mdhip_
   void *flag = nullptr;
   MD_TRY(mdhip_alloc(sizeof(int), &flag));
   (void)hipMemsetAsync(flag, 0, sizeof(int), md_stream());
+  void *census = nullptr;
   {
-    int64_t L = 0, P = 0;
-    if (run_geometry(pl, &L, &P)) k_check_bounds<<<md_grid_for(P), MD_BLOCK, 0, md_stream()>>>(*pl, P, L, (int *)flag);
-    else k_check_bounds<<<md_grid_for(total), MD_BLOCK, 0, md_stream()>>>(*pl, total, 1, (int *)flag);
+    int64_t L = 0, P = 0, unit = 1;
+    if (run_geometry(pl, &L, &P, &unit)) {
+      int64_t lo, hi;
+      run_key_range(pl, L, &lo, &hi);
+      const int64_t nkeys = (hi - lo) / unit + 1;
+      static const bool census_on = [] { const char *e = getenv("MDHIP_SCATTER_CENSUS"); return !(e && e[0] == '0'); }();   // 0: always sort (A/B)
+      if (census_on && total > 4096 && nkeys > 0 && nkeys <= (1ll << 22) && mdhip_alloc((size_t)nkeys * sizeof(int), &census) == MDHIP_OK) {
+        (void)hipMemsetAsync(census, 0, (size_t)nkeys * sizeof(int), md_stream());
+        k_check_bounds_dups<<<md_grid_for(P), MD_BLOCK, 0, md_stream()>>>(*pl, P, L, lo, unit, (int *)census, (int *)flag);
+      } else {
+        census = nullptr;
+        k_check_bounds<<<md_grid_for(P), MD_BLOCK, 0, md_stream()>>>(*pl, P, L, (int *)flag);
+      }
+    } else {
+      k_check_bounds<<<md_grid_for(total), MD_BLOCK, 0, md_stream()>>>(*pl, total, 1, (int *)flag);
+    }
   }
-  int bad = 0;
-  int rc = read_flag((int *)flag, &bad);
+  int bits = 0;
+  int rc = read_flag((int *)flag, &bits);
   mdhip_free(flag);
+  const bool unique_rows = census != nullptr && (bits & 2) == 0;
+  if (census) mdhip_free(census);
   if (rc != MDHIP_OK) return rc;
-  if (bad) return md_fail(MDHIP_EINDEX, "index is out of bounds for the indexed axis");
+  if (bits & 1) return md_fail(MDHIP_EINDEX, "index is out of bounds for the indexed axis");
   switch (dtype) {
-    case MDHIP_BOOL: return scatter_typed<uint8_t>(pl, total, dst, val, mode);
-    case MDHIP_I32: return scatter_typed<int32_t>(pl, total, dst, val, mode);
-    case MDHIP_I64: return scatter_typed<int64_t>(pl, total, dst, val, mode);
-    case MDHIP_F32: return scatter_typed<float>(pl, total, dst, val, mode);
-    case MDHIP_F64: return scatter_typed<double>(pl, total, dst, val, mode);
+    case MDHIP_BOOL: return scatter_typed<uint8_t>(pl, total, dst, val, mode, unique_rows);
+    case MDHIP_I32: return scatter_typed<int32_t>(pl, total, dst, val, mode, unique_rows);
+    case MDHIP_I64: return scatter_typed<int64_t>(pl, total, dst, val, mode, unique_rows);
+    case MDHIP_F32: return scatter_typed<float>(pl, total, dst, val, mode, unique_rows);
+    case MDHIP_F64: return scatter_typed<double>(pl, total, dst, val, mode, unique_rows);
   }
   return md_fail(MDHIP_ETYPE, "scatter: bad dtype code %d", dtype);
 }
