@@ -917,12 +917,12 @@ def _binary(ufunc, code, a, b, out=None):
         wb = astype(b, _narrow._WIDE.get(loop[1], loop[1])) if b_arr else b
         res = _binary(ufunc, code, wa, wb)
         return res if res.dtype == odt else _convert(res, odt)
-    if code == _capi.B_POW and cdt.kind == "i":
-        _check_int_power(b)
     if a_arr and b_arr:
         shape = _broadcast_shapes(a.shape, b.shape)
     else:
         shape = a.shape if a_arr else b.shape
+    if code == _capi.B_POW and cdt.kind == "i" and _prod(shape) > 0:
+        _check_int_power(b)      # (NumPy raises from inside its loop: an EMPTY result never meets the negative exponent)
     if _LAZY and out is None:
         pcdt = _FLOAT_DT.get(cdt)
         if pcdt is None and cdt.kind == "b" and code >= _capi.B_LAND:

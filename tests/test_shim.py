@@ -107,3 +107,21 @@ def _overlap_case(nd_unused):
 def test_inplace_overlap_cpu(lib, on_gpu): _run(lib, on_gpu, False, _overlap_case)
 @gpu
 def test_inplace_overlap_gpu(lib, on_gpu): _run(lib, on_gpu, True, _overlap_case)
+
+
+def test_integer_power_with_negative_exponents(lib):
+    """NumPy raises "Integers to negative integer powers are not allowed" from INSIDE its loop: a non-empty result raises (array or
+    scalar exponent), an EMPTY one never meets the exponent and is returned (fuzz seed 92, case 5327)."""
+    from minidiff_amd import ndarray as nd
+    base = nd.asarray(np.arange(1, 7, dtype=np.int64).reshape(2, 3))
+    neg = nd.asarray(np.array([1, -2, 3], dtype=np.int32))
+    with pytest.raises(ValueError, match="negative integer powers"):
+        nd.power(base, neg)
+    with pytest.raises(ValueError, match="negative integer powers"):
+        nd.power(base, -3)
+    empty = nd.asarray(np.zeros((0, 2, 3), dtype=np.int64))
+    for e in (neg, -3):
+        got = nd.power(empty, e)
+        exp = np.power(empty.get(), e.get() if isinstance(e, nd.DeviceArray) else e)
+        assert got.shape == exp.shape and got.dtype == exp.dtype
+    np.testing.assert_array_equal(nd.power(base, nd.asarray(np.array([0, 2, 3], dtype=np.int32))).get(), np.power(base.get(), np.array([0, 2, 3], dtype=np.int32)))
