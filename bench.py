@@ -21,9 +21,17 @@ same job (the driver's N = 1 run is cfg2: another workload). `--workload cfg2` a
 variant (every rank owns its own 4096-row block A_r; B.grad all-reduced); it is
 also run after the headline and reported under "secondary".
 
-One JSON line on stdout (rank 0). `roofline` prices the dominant kernel from HIP
-events recorded on the library's stream inside the timed region; `cpu_baseline`
-times the NumPy oracle (the reference's arithmetic) on this host's cores.
+`python bench.py --gpus N` with N > 1 and no rank environment starts its own N ranks
+(one child process per GPU, before anything in THIS process touches the GPU), forwards
+rank 0's line and exits non-zero if any rank fails or the job exceeds --rank-timeout.
+At N > 1 the gradient all-reduce must run on the library's own RCCL communicator
+("rccl-direct"); anything else is an error unless --allow-torch-comm is given.
+
+ONE JSON line on stdout (rank 0), under 2 KB: `roofline` prices the dominant kernel from
+HIP events attached to the kernel's own dispatch inside the timed region and carries, as
+FLAT scalar keys, the figures of the other BASELINE configs (cfgN_*); `cpu_baseline` times
+the NumPy oracle (the reference's arithmetic) on this host's cores for every config. The
+full per-kernel detail goes to bench_detail.json (next to this file) and to stderr.
 """
 from __future__ import annotations
 
@@ -54,12 +62,92 @@ def parse():
     ap.add_argument("--size", type=int, default=0, help="override the problem size (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="only the headline workload")
+    ap.add_argument("--force-secondary", action="store_true", help="run the other configs even with --size (tests: toy sizes on the CPU double)")
     ap.add_argument("--lazy", action="store_true",
                     help="opt-in lazy fusion of elementwise chains (minidiff_amd/lazy.py); default is eager")
     ap.add_argument("--graph", action="store_true",
                     help="capture one sweep into a hipGraph after warm-up and time K replays of it (N=1 only)")
     ap.add_argument("--comm", default=os.environ.get("MDHIP_COMM", "rccl"), choices=["rccl", "torch"])
+    ap.add_argument("--allow-torch-comm", action="store_true",
+                    help="N > 1: accept torch.distributed's RCCL backend when the library's own communicator cannot be built "
+                         "(default: that is an error — the panelled, overlapped all-reduce would not be what ran)")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0, help="self-spawned N > 1 job: seconds before the ranks are killed")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), help="where the full per-kernel detail is written")
     return ap.parse_args()
+
+
+def spawn_ranks(args, entry):
+    """`python bench.py --gpus N` without a launcher: start N copies of `entry` (one per GPU) with the rank environment
+    torch.distributed.run would set, forward rank 0's JSON line, and fail loudly — every rank killed, non-zero exit — if
+    one rank dies or the job exceeds --rank-timeout. Runs BEFORE anything in this process touches the GPU and never
+    replaces a process (no os.exec*): the parent only waits."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs, out0 = [], []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, entry] + sys.argv[1:], env=env, start_new_session=True,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr, stderr=None, text=(rank == 0)))
+
+    def pump():
+        for ln in procs[0].stdout:
+            out0.append(ln)
+
+    reader = threading.Thread(target=pump, daemon=True)
+    reader.start()
+
+    def kill_all():
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            for p in procs:
+                if p.poll() is None:
+                    try:
+                        os.killpg(p.pid, sig)      # (start_new_session: the child leads its own group — its helpers go with it)
+                    except (ProcessLookupError, PermissionError):
+                        pass
+            t_end = time.time() + 5.0
+            while time.time() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.05)
+
+    deadline = time.time() + args.rank_timeout
+    failed = None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                failed = f"no result within --rank-timeout {args.rank_timeout:.0f} s"
+                break
+            time.sleep(0.1)
+    except BaseException as e:   # (Ctrl-C, a signal from the driver: do not leave ranks behind)
+        failed = f"interrupted ({type(e).__name__})"
+    if failed:
+        kill_all()
+        print(f"[bench] {n}-rank job FAILED: {failed}; all ranks killed", file=sys.stderr)
+        return 124 if failed.startswith("no result") else 1
+    reader.join(timeout=10.0)
+    lines = [ln for ln in out0 if ln.startswith("{")]
+    if len(lines) != 1:
+        print(f"[bench] {n}-rank job printed {len(lines)} JSON lines (expected 1)", file=sys.stderr)
+        return 1
+    sys.stdout.write(lines[0] if lines[0].endswith("\n") else lines[0] + "\n")
+    sys.stdout.flush()
+    return 0
 
 
 class KernelTimer:
@@ -189,6 +277,8 @@ def cpu_baseline(workload, size):
     else:
         if size:
             kw["batch"] = size
+        if os.environ.get("MDHIP_BENCH_CFG4_DIM"):   # tests only (as in run())
+            kw["d_in"] = kw["d_out"] = int(os.environ["MDHIP_BENCH_CFG4_DIM"])
         sample = "full cfg4 sweep (global batch on one host), best of 3 after 1 warm-up"
         reps = 3
     state, step = workloads.MAKERS[workload](md, **kw)
@@ -207,7 +297,7 @@ def cpu_baseline(workload, size):
     grads = {name: np.asarray(state[name].grad.as_numpy()) for name in GRAD_NAMES[workload]}
     return {
         "value": scale / best, "unit": "passes/s", "cores": cores, "kind": "port",
-        "sample": sample + f"; numpy {np.__version__}; GEMM threads = all cores, ufuncs single-threaded",
+        "sample": sample + f"; numpy {np.__version__}; GEMM all cores, ufuncs 1 thread",
     }, grads
 
 
@@ -235,10 +325,10 @@ DEFAULT_SIZE = {"cfg2": 4096, "cfg3": 100_000_000, "cfg4": 8192, "cfg5": 2048}
 def describe(workload, n, lazy):
     mode = " [lazy fusion]" if lazy else ""
     return {
-        "cfg2": f"cfg2: C=A@B ({n}x{n} fp32), C.backward(); 3 GEMMs NN/NT/TN; per-rank batch block, B.grad all-reduced" + mode,
+        "cfg2": f"cfg2: C=A@B ({n}x{n} fp32), C.backward(); 3 GEMMs NN/NT/TN" + mode,
         "cfg3": f"cfg3: sum((sin(x)*y)**2).backward(), N={n} fp32" + (mode if lazy else " [eager: 11 kernels]"),
-        "cfg4": f"cfg4: sum(relu(X@W+b)).backward(), global batch {n} x 4096 -> 4096, row-sharded" + mode,
-        "cfg5": f"cfg5: second order on {n}x{n} matmul, 5 GEMMs" + (" [lazy: products whose result nothing reads (the first-order B.grad) are never launched — NOT the 5-GEMM workload]" if lazy else ""),
+        "cfg4": f"cfg4: sum(relu(X@W+b)).backward(), batch {n} x 4096 -> 4096, row-sharded" + mode,
+        "cfg5": f"cfg5: second order on {n}x{n} matmul, 5 GEMMs" + (" [lazy: unread products are never launched - NOT the 5-GEMM workload]" if lazy else ""),
     }[workload]
 
 
@@ -246,15 +336,25 @@ def _mean(v):
     return sum(v) / len(v) if v else None
 
 
-def _hbm(kernel, nbytes, ms, **extra):
+def _hbm(kernel, nbytes, ms, durs=None, **extra):
     ach = nbytes / (ms * 1e-3) / 1e9
     d = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
          "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms}
+    if durs:
+        d.update(_stats(durs))
     d.update(extra)
     return d
 
 
-def rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc, n_bracketed=0):
+def _stats(v):
+    """mean / min / median of a list of launch durations (ms)."""
+    if not v:
+        return {}
+    w = sorted(v)
+    return {"avg_launch_ms": sum(w) / len(w), "min_launch_ms": w[0], "median_launch_ms": w[len(w) // 2]}
+
+
+def rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc, n_bracketed=0, dma=True):
     """-> (roofline of the dominant kernel, extra per-kernel detail) from the HIP-event durations of the timed region."""
     per_sweep = kernel_ms.pop("_per_sweep", None)
     detail = {k: {"launches": len(v), "avg_ms": _mean(v)} for k, v in sorted(kernel_ms.items())}
@@ -265,10 +365,9 @@ def rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc, n
         main = None
         # in lazy mode the weight-gradient matmul call also launches the fused pass that produces its operand:
         # price the GEMM on the calls that contain nothing else
-        # (16-B aligned operands and whole tiles — every BASELINE shape — run the direct-to-LDS kernels; MDHIP_GEMM_GLDS=0 or a
-        # ragged shape the register-staged k_gemm_f32_mfma)
-        dma = os.environ.get("MDHIP_GEMM_GLDS", "1") != "0"
-        gemm_kernel = "k_gemm_f32_kc_glds (NN, NT) / k_gemm_f32_tn_glds (TN)" if dma else "k_gemm_f32_mfma"
+        # (16-B aligned operands and whole tiles — every BASELINE shape — run the direct-to-LDS kernels; the option gemm_glds = 0
+        # (experiments) or a ragged shape the register-staged k_gemm_f32_mfma)
+        gemm_kernel = "k_gemm_f32_kc_glds (NN,NT) / k_gemm_f32_tn_glds (TN)" if dma else "k_gemm_f32_mfma"
         if workload == "cfg4" and lazy:
             # lazy mode defers the products: the forward GEMM runs inside the loss reduction with the bias / relu / sum
             # epilogue (bracket "sum_all": one launch, the last block sums the per-block relu sums), the weight-gradient GEMM when W.grad is materialised
@@ -292,7 +391,7 @@ def rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc, n
                     "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
                     "traffic": None,  # not measured in this run (PMC passes need the profiler)
                     "traffic_committed": committed, "traffic_committed_source": pmc.get("_source") if committed else None,
-                    "launches": len(durs), "avg_launch_ms": avg, "flop_per_launch": flop_per_launch,
+                    "launches": len(durs), **_stats(durs), "flop_per_launch": flop_per_launch,
                     "algorithmic_bytes_per_launch": 3 * 4 * (size or 4096) ** 2 if workload == "cfg2" else None}
         if workload == "cfg4":
             rows, cols = state["rows"], 4096
@@ -305,7 +404,7 @@ def rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc, n
                                           ("multiply", "mask product g*mask (f32 x bool)", 5 * e),
                                           ("sum_cols", "column sum (bias gradient, reduce-to-shape)", 4 * e + 4 * cols)):
                     if kernel_ms.get(tag):
-                        tail[tag] = _hbm(name, nbytes, _mean(kernel_ms[tag]))
+                        tail[tag] = _hbm(name, nbytes, _mean(kernel_ms[tag]), durs=kernel_ms[tag])
                 if "multiply" in tail and "sum_cols" in tail:
                     ms = tail["multiply"]["avg_launch_ms"] + tail["sum_cols"]["avg_launch_ms"]
                     tail["backward_pair"] = _hbm("elementwise + reduce-to-shape backward: mask product (k_ew_fast), then column sum (k_reduce_cols_strips): one launch each",
@@ -345,18 +444,32 @@ def rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc, n
         tot_ms = sum(c * m for c, m in (per_sweep or {}).values()) or sum(sum(v) for v in kernel_ms.values())
         steps = 1 if per_sweep else (len(kernel_ms.get("sin", [])) or 1)
         committed = pmc_mean(pmc, "k_ew_fast<BinaryBody<BMul, float, float, float, float, 1, 1, true>") if not size else None
-        main = _hbm("k_ew_fast<BinaryBody<BMul,f32,f32>> (multiply, both operands streamed)", 12 * n, avg, launches=len(durs),
+        main = _hbm("k_ew_fast<BinaryBody<BMul,f32,f32>> (multiply, both operands streamed)", 12 * n, avg, durs=durs, launches=len(durs),
                     traffic_committed=committed, traffic_committed_source=pmc.get("_source") if committed else None,
                     whole_sweep={"algorithmic_bytes": state["bytes"], "kernel_ms": tot_ms / steps,
                                  "GB/s": state["bytes"] * steps / (tot_ms * 1e-3) / 1e9,
                                  "frac": state["bytes"] * steps / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+    chain = {}
+    for tag, nbytes in (("sin", 8 * n), ("cos", 8 * n), ("power", 8 * n), ("sum_all", 4 * n), ("multiply_scalar", 4 * n)):
+        if kernel_ms.get(tag):
+            chain[tag] = _hbm(tag, nbytes, _mean(kernel_ms[tag]), durs=kernel_ms[tag])
+    detail["chain"] = chain
     return main, detail
 
 
-def compact_secondary(secondary):
-    """Per-config roofline fractions in a few numbers each: the driver keeps `roofline` whole and only the NAMES of other
-    top-level keys. frac = share of 157.3 TFLOP/s (GEMM kernels) or of 8 TB/s (streaming kernels, algorithmic bytes of
-    SURVEY 8d); kernel durations are the kernels' own dispatch timestamps (event-attached), ms = average per launch."""
+def _r(x, sig=5):
+    """Numbers in the stdout line carry `sig` significant digits (the line stays under 2 KB; bench_detail.json has them all)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float(f"{x:.{sig}g}")
+
+
+def flat_keys(results):
+    """The other BASELINE configs as FLAT scalar keys for `roofline` (the driver's record keeps scalars of `roofline`, `config`
+    and `cpu_baseline` and only the NAMES of anything nested or top-level): passes/s per config, and for every kernel a
+    verdict prices — fraction of peak (157.3 TFLOP/s for GEMM kernels, 8 TB/s of ALGORITHMIC bytes, SURVEY 8d, for streaming
+    kernels), mean duration in us (the kernel's own dispatch timestamps) and the bytes / flop it is priced on, so that every
+    fraction can be recomputed from the record alone. `results`: {"cfg3": run result, "cfg3_lazy": .., "cfg4": .., ..}."""
     def pick(d, *path):
         for k in path:
             if not isinstance(d, dict) or d.get(k) is None:
@@ -364,34 +477,69 @@ def compact_secondary(secondary):
             d = d[k]
         return d
 
-    def kern(r):
-        return None if r is None else {"frac": r.get("frac"), "ms": r.get("avg_launch_ms"), "bytes": r.get("algorithmic_bytes_per_launch")}
+    f = {}
 
-    out = {}
-    for name, r in secondary.items():
-        if "error" in r:
-            out[name] = {"error": r["error"]}
+    def put(key, v):
+        if v is not None:
+            f[key] = v
+
+    def kern(prefix, r, us=True, nbytes=False):
+        if not r:
+            return
+        put(prefix + "_frac", r.get("frac"))
+        if us and r.get("avg_launch_ms") is not None:
+            put(prefix + "_us", r["avg_launch_ms"] * 1e3)
+        if nbytes:
+            put(prefix + "_bytes", r.get("algorithmic_bytes_per_launch"))
+
+    for name, r in results.items():
+        if not r or "error" in r:
+            f[name + "_error"] = 1
             continue
-        c = {"passes_per_s": r["value"], "ms_per_step": r["ms_per_step"], "bound": pick(r, "roofline", "bound"),
-             "frac": pick(r, "roofline", "frac"), "achieved": pick(r, "roofline", "achieved"), "unit": pick(r, "roofline", "unit")}
-        tail = pick(r, "kernels", "hbm_tail") or {}
-        for key, short in (("backward_pair", "pair"), ("sum_all", "loss_sum"), ("sum_cols", "colsum"), ("multiply", "maskprod"),
-                           ("add", "bias_add"), ("greater", "greater"), ("where", "where")):
-            if key in tail:
-                c[short] = kern(tail[key])
-        fused = pick(r, "kernels", "fused_kernels") or {}
-        for key in ("loss_pass", "gradient_pass"):
-            if key in fused:
-                c[key] = kern(fused[key])
-        ws = pick(r, "roofline", "whole_sweep")
-        if ws:
-            c["whole_sweep_frac"] = ws.get("frac")
-        out[name] = c
-    return out
+        put(name + "_passes_per_s", r["value"])
+        roof = r.get("roofline") or {}
+        if name == "cfg3":
+            kern("cfg3_mul", roof, nbytes=True)
+            put("cfg3_whole_sweep_frac", pick(roof, "whole_sweep", "frac"))
+            chain = pick(r, "kernels", "chain") or {}
+            kern("cfg3_sin", chain.get("sin"))
+            kern("cfg3_cos", chain.get("cos"), us=False)
+            kern("cfg3_loss_sum", chain.get("sum_all"), us=False)
+        elif name == "cfg3_lazy":
+            put("cfg3_lazy_frac", roof.get("frac"))                     # whole sweep: 24N bytes / wall time
+            fused = pick(r, "kernels", "fused_kernels") or {}
+            kern("cfg3_lazy_loss_pass", fused.get("loss_pass"), us=False)
+            kern("cfg3_lazy_grad_pass", fused.get("gradient_pass"), us=False)
+        elif name in ("cfg4", "cfg4_lazy"):
+            put(name + "_gemm_frac", roof.get("frac"))
+            tail = pick(r, "kernels", "hbm_tail") or {}
+            kern(name + "_pair", tail.get("backward_pair"), nbytes=True)
+            if name == "cfg4":
+                kern("cfg4_loss_sum", tail.get("sum_all"))
+                kern("cfg4_colsum", tail.get("sum_cols"))
+                kern("cfg4_maskprod", tail.get("multiply"))
+                kern("cfg4_bias_add", tail.get("add"), us=False)
+                kern("cfg4_where", tail.get("where"), us=False)
+                kern("cfg4_greater", tail.get("greater"), us=False)
+        elif name in ("cfg5", "cfg2", "cfg2_weak", "cfg4_strong"):
+            put(name + "_frac", roof.get("frac"))
+            if roof.get("avg_launch_ms") is not None:
+                put(name + "_gemm_us", roof["avg_launch_ms"] * 1e3)
+    return f
 
 
-def main():
+# keys of `roofline` given up first when the line would pass 2 KB (everything stays in bench_detail.json)
+DROP_ORDER = ["cfg4_greater_frac", "cfg4_where_frac", "cfg3_cos_frac", "cfg3_loss_sum_frac", "traffic_committed_source", "min_launch_ms",
+              "cfg3_lazy_loss_pass_frac", "cfg3_lazy_grad_pass_frac", "cfg4_lazy_gemm_frac", "cfg4_bias_add_frac", "cfg3_mul_bytes",
+              "cfg4_lazy_pair_bytes", "launches", "median_launch_ms", "cfg3_sin_us", "cfg4_maskprod_us", "cfg4_colsum_us"]
+
+
+def main(entry=None):
+    """`entry`: the script a self-spawned rank runs (default: this file; tests pass their own wrapper)."""
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # no launcher around us: be the launcher (nothing in this process has touched the GPU yet, and nothing will)
+        raise SystemExit(spawn_ranks(args, entry or os.path.abspath(__file__)))
     # Only the JSON line may reach stdout: libraries print banners there (RCCL's version block, gloo's "connected to N peer
     # ranks"). File descriptor 1 points at stderr until the line is printed.
     sys.stdout.flush()
@@ -401,8 +549,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is what runs", file=sys.stderr)
         args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["MDHIP_DEVICE"] = str(local_rank)
@@ -494,12 +642,29 @@ def main():
                     if comm is not None:
                         comm.close()
                         comm = None
-                    print(f"[rank {rank}] direct RCCL communicator unavailable ({err or 'failed on another rank'}); "
-                          "using torch.distributed nccl", file=sys.stderr)
+                    why = f"[rank {rank}] direct RCCL communicator unavailable ({err or 'failed on another rank'})"
+                    if not args.allow_torch_comm:
+                        # every rank takes this branch together (the flags were all-gathered): the job ends with rc != 0 instead
+                        # of a line measured on a host-synchronous fallback that nobody asked for
+                        print(why + "; refusing to fall back (pass --allow-torch-comm to accept torch.distributed's backend)", file=sys.stderr)
+                        raise SystemExit(3)
+                    print(why + "; using torch.distributed nccl (--allow-torch-comm)", file=sys.stderr)
+            elif not args.allow_torch_comm and world > 1:
+                print("[bench] --comm torch at N > 1 needs --allow-torch-comm (the product path is the library's own RCCL communicator)", file=sys.stderr)
+                raise SystemExit(3)
             if comm is None:  # same data path through torch's RCCL
                 comm = dp.TorchComm(rank, world, dist, torch)
                 kind = "rccl-torch"
         return comm, kind
+
+    def rccl_ranks(comm):
+        """What ncclCommCount says about the live communicator (None: not the direct RCCL path)."""
+        if not isinstance(comm, dp.RcclComm):
+            return None
+        import ctypes as C
+        n = C.c_int(0)
+        lib.comm_count(C.byref(n))
+        return int(n.value)
 
     def run(workload, lazy, steps, warmup, graph=False, size=0, keep=None, solo=False, want_grads=False):
         """One workload: pre-roll, W warm-up sweeps, K timed sweeps between barriers, max over ranks.
@@ -528,6 +693,9 @@ def main():
             if keep is not None:
                 keep["state"], keep["step"] = state, step
         comm, comm_kind = (None, "none") if solo else make_comm(workload)
+        n_rccl = rccl_ranks(comm)
+        if n_rccl is not None and n_rccl != world:
+            raise SystemExit(f"[bench] the RCCL communicator reports {n_rccl} ranks, the job has {world}")
         sync = dp.GradSync(md, state["params"] if workload == "cfg4" else state["params"][:1], comm, force=force_dist,
                            overlap=os.environ.get("MDHIP_DP_OVERLAP", "1") != "0")
 
@@ -670,8 +838,11 @@ def main():
             value, scaling = steps / elapsed, "strong"
         else:
             value, scaling = world * steps / elapsed, "weak"
+        import ctypes as _C
+        glds = _C.c_int64(1)
+        lib.debug_get_option(b"gemm_glds", _C.byref(glds))
         roof, detail = rooflines(workload, lazy, state, kernel_ms, ms_per_step, size, world, pmc,
-                                 n_bracketed=(max(warmup, 1) if (graph or segmented) else steps))
+                                 n_bracketed=(max(warmup, 1) if (graph or segmented) else steps), dma=bool(glds.value))
         n = size or DEFAULT_SIZE[workload]
         res = {
             "value": value, "unit": "passes/s", "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup, "preroll_sweeps": preroll,
@@ -679,7 +850,7 @@ def main():
             "single_sweep_ms": {"median": single[len(single) // 2], "min": single[0], "n": len(single)} if single else None,
             "config": {"workload": describe(workload, n, lazy), "parallelism": f"dp{world}", "lazy_fusion": bool(lazy),
                        "graph_replay": bool(graph) or ({"segments": captured.segments, "collective_calls": captured.calls} if segmented else False),
-                       "collective": comm_kind, "allreduce_bytes": sync.nbytes if use_dist else 0,
+                       "collective": comm_kind, "rccl_ranks": n_rccl, "allreduce_bytes": sync.nbytes if use_dist else 0,
                        "allreduce_overlapped_sweeps": sync.overlapped, "allreduce_panels": getattr(sync, "panels", 1),
                        "allreduce_alone_ms": allreduce_ms, "allreduce_busbw_GBps": busbw},
             "roofline": roof, "kernels": detail,
@@ -715,16 +886,27 @@ def main():
         gc.collect()
         lib.empty_cache()
 
-    cpu = linf = None
+    # ---- CPU leg (rank 0, N = 1): the NumPy engine on the same seeds, once per WORKLOAD — its passes/s (the reported baseline)
+    # and its gradients, against which every device run of that workload (eager and lazy) is compared norm-wise
+    cpu_all, linf_all, oracle_cache = {}, {}, {}
+
+    def cpu_leg(name, workload, device_grads):
+        if workload not in oracle_cache:
+            oracle_cache.clear()            # (one workload's oracle gradients at a time: cfg3's sample alone is 80 MB)
+            c, og = cpu_baseline(workload, args.size)
+            cpu_all[workload] = c
+            oracle_cache[workload] = og
+        if device_grads is not None:
+            linf_all[name] = grad_linf_rel(device_grads, oracle_cache[workload])
+
+    head_name = args.workload + ("_lazy" if args.lazy else "")
     if check_grads:
-        cpu, oracle_grads = cpu_baseline(args.workload, args.size)
-        if head_grads is not None:
-            linf = grad_linf_rel(head_grads, oracle_grads)
-        head_grads = oracle_grads = None
+        cpu_leg(head_name, args.workload, head_grads)
+    head_grads = None
 
     # ---- the other BASELINE configs, same process, after the headline's timed region -------------------
     secondary = None
-    if not args.no_secondary and not args.graph and (not args.size or os.environ.get("MDHIP_BENCH_HOST_COMM") == "1"):
+    if not args.no_secondary and not args.graph and (not args.size or args.force_secondary or os.environ.get("MDHIP_BENCH_HOST_COMM") == "1"):
         secondary = {}
         gc.collect()
         lib.empty_cache()
@@ -742,8 +924,11 @@ def main():
                 gc.collect()
                 lib.empty_cache()
             try:
-                r = run(wl, lz, k_sec, w_sec, size=args.size, keep=keep)
-                r.pop("kernels" if wl in ("cfg2", "cfg5") else "_none", None)
+                r = run(wl, lz, k_sec, w_sec, size=args.size, keep=keep, want_grads=check_grads)
+                grads = r.pop("_grads", None)
+                if check_grads:
+                    cpu_leg(name, wl, grads)
+                grads = None
                 secondary[name] = r
             except Exception as e:  # a secondary config must never take the headline down
                 # (N > 1 too: a failure that every rank hits at the same point — the deterministic kind — is recorded and the
@@ -751,39 +936,82 @@ def main():
                 secondary[name] = {"error": f"{type(e).__name__}: {e}"}
                 print(f"[bench] secondary {name} failed: {type(e).__name__}: {e}", file=sys.stderr)
         keep = None
+        oracle_cache.clear()
         gc.collect()
 
     nd.DeviceArray._materialize = _plain_materialize
     if rank == 0:
+        results = {head_name: head}
+        results.update(secondary or {})
+        flat = flat_keys({k: v for k, v in results.items() if k != head_name or head_name != "cfg2"})
+        linf_max = max((v for d in linf_all.values() for v in d.values()), default=None)
+        roof = dict(head["roofline"] or {})
+        roof = {k: v for k, v in roof.items() if not isinstance(v, (dict, list))}    # scalars only: what the driver's record keeps
+        if roof.get("traffic_committed_source"):
+            roof["traffic_committed_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc passes)"
+        for k in ("note", "algorithmic_bytes_per_launch"):    # (derivable: 3 x 4 N^2; in the detail file)
+            roof.pop(k, None)
+        if roof.get("traffic_committed") is None:
+            roof.pop("traffic_committed", None)
+            roof.pop("traffic_committed_source", None)
+        roof.update(flat)
+        if linf_max is not None:
+            roof["grad_linf_rel_max"] = linf_max
+        for wl, c in cpu_all.items():
+            roof[f"cpu_{wl}_passes_per_s"] = c["value"]
+        cpu = None
+        if args.workload in cpu_all:
+            cpu = dict(cpu_all[args.workload])
+            for wl, c in cpu_all.items():      # the NumPy engine on every config (cfg3: N = 1e7 sample, scaled linearly)
+                if wl != args.workload:
+                    cpu[f"{wl}_value"] = c["value"]
+        cfg = {k: v for k, v in head["config"].items() if not isinstance(v, (dict, list))}
+        if not use_dist:   # (one GPU: no collective — the all-reduce fields would only say so)
+            cfg = {k: v for k, v in cfg.items() if not k.startswith("allreduce_") and k != "rccl_ranks"}
+        if isinstance(head["config"].get("graph_replay"), dict):
+            cfg["graph_replay"] = True
+            cfg["graph_segments"] = head["config"]["graph_replay"]["segments"]
         line = {
             "metric": "forward+backward passes/sec on 4096x4096 fp32 matmul+elementwise graph",
             "value": head["value"], "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "preroll_sweeps": head["preroll_sweeps"],
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": head["config"],
-            "roofline": head["roofline"], "cpu_baseline": cpu,
-            "single_sweep_ms": head["single_sweep_ms"],
+            "config": cfg, "roofline": roof, "cpu_baseline": cpu,
+            # the metric's second half: max over every gradient of every config run, norm-wise against the NumPy engine
+            # on the same seeds (bar 1e-5 for fp32). None when the CPU leg is skipped (N > 1, --no-cpu-baseline).
+            "grad_linf_rel_max": linf_max,
         }
-        # the metric's second half: gradients of the headline sweep against the NumPy engine on the same seeds
-        # (norm-wise; bar 1e-5 for fp32). None when the CPU leg is skipped (N > 1, --no-cpu-baseline).
-        line["grad_linf_rel"] = linf
-        if secondary and line["roofline"] is not None:
-            line["roofline"]["secondary"] = compact_secondary(secondary)
         if "tensors_per_s" in head:
             line["tensors_per_s"] = head["tensors_per_s"]
         if solo is not None:
-            line["single_gpu_same_workload"] = solo
-        if args.workload != "cfg2" or args.lazy:
-            line["kernels"] = head["kernels"]
-        # per-kernel durations are HIP-event brackets around one backend call: they include the markers' own cost
-        # (this figure) and the launch gaps of multi-kernel calls; profiles/ holds the rocprofv3 kernel times
-        line["event_bracket_overhead_ms"] = event_overhead_ms
-        if secondary is not None:
-            line["secondary"] = secondary
+            line["single_gpu_value"] = solo["value"]
+            if "tensors_per_s" in solo:
+                line["single_gpu_tensors_per_s"] = solo["tensors_per_s"]
+        detail = {"line": line, "head": head, "secondary": secondary, "cpu_baseline": cpu_all, "grad_linf_rel": linf_all,
+                  "single_gpu_same_workload": solo, "preroll_sweeps": head["preroll_sweeps"], "single_sweep_ms": head["single_sweep_ms"],
+                  # per-kernel durations are the kernels' own dispatch timestamps; a marker bracket (only where a call launches
+                  # no attachable kernel) costs this much stream time
+                  "event_bracket_overhead_ms": event_overhead_ms}
+        # ---- the stdout line: < 2 KB (the driver keeps the last 2 KB of stdout and the scalars of roofline / config / cpu_baseline)
+        def rounded(o):
+            if isinstance(o, dict):
+                return {k: rounded(v) for k, v in o.items()}
+            return _r(o)
+        out = rounded(line)
+        drop = list(DROP_ORDER)
+        text = json.dumps(out, separators=(",", ":"))
+        while len(text) > 2000 and drop:
+            out["roofline"].pop(drop.pop(0), None)
+            text = json.dumps(out, separators=(",", ":"))
+        try:
+            with open(args.detail, "w") as fh:
+                json.dump(detail, fh, indent=1, default=str)
+        except OSError as e:
+            print(f"[bench] could not write {args.detail}: {e}", file=sys.stderr)
+        print("[bench-detail] " + json.dumps(detail, default=str), file=sys.stderr)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
-        print(json.dumps(line))
+        print(text)
         sys.stdout.flush()
     if use_dist:
         dist.destroy_process_group()

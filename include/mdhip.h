@@ -146,6 +146,15 @@ enum {
  * allocator. Idempotent for the same device. */
 int mdhip_init(int device);
 int mdhip_device(int *device_out);
+/* Undo mdhip_init (stream, ticket block, cached device blocks). MDHIP_ERUNTIME while device blocks are still live. */
+int mdhip_shutdown(void);
+/* TEST / A-B HOOK. libmdhip's tuning switches (tile forcing, staging scheme, legacy two-launch reductions, ...) live in one
+ * table (csrc/md_options.h). Without MDHIP_EXPERIMENTS=1 in the environment the library ignores every MDHIP_GEMM_* /
+ * MDHIP_*_TICKET / MDHIP_COLS_* / MDHIP_ARG_* / MDHIP_SWEEP_* variable and never calls getenv on a launch path; tests that
+ * must force a kernel set the table entry through this call (name = the entry's lower-case name, e.g. "gemm_cfg"), effective
+ * from the next launch. Unknown name: MDHIP_EVALUE. No reference counterpart (the reference has no native code). */
+int mdhip_debug_set_option(const char *name, int64_t value);
+int mdhip_debug_get_option(const char *name, int64_t *value_out);
 /* "hip:gfx950" for the product library; the CPU test double under oracle/
  * answers "host". The shim refuses to run product code on anything else. */
 const char *mdhip_target(void);
@@ -373,6 +382,8 @@ int mdhip_vm_jit_stats(int64_t stats[2]);
 /* Can this process reach RCCL at all (opens librccl; creates nothing)? Ranks agree on the answer BEFORE
  * ncclCommInitRank, which would wait for the missing ones for ever (minidiff_amd/dp.py RcclComm). */
 int mdhip_comm_probe(void);
+/* Number of ranks of the live communicator, as RCCL reports it (ncclCommCount). */
+int mdhip_comm_count(int *nranks_out);
 int mdhip_comm_get_unique_id(uint8_t uid[MDHIP_UID_BYTES]);
 int mdhip_comm_init(int nranks, int rank, const uint8_t uid[MDHIP_UID_BYTES]);
 int mdhip_comm_allreduce_sum(void *buf, size_t count, int dtype); /* in place, on the stream */

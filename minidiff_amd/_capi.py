@@ -91,6 +91,9 @@ _P = C.POINTER
 _PROTOTYPES = {
     "mdhip_init": [C.c_int],
     "mdhip_device": [_P(C.c_int)],
+    "mdhip_shutdown": [],
+    "mdhip_debug_set_option": [C.c_char_p, C.c_int64],
+    "mdhip_debug_get_option": [C.c_char_p, _P(C.c_int64)],
     "mdhip_alloc": [C.c_size_t, _P(C.c_void_p)],
     "mdhip_free": [C.c_void_p],
     "mdhip_empty_cache": [],
@@ -135,6 +138,7 @@ _PROTOTYPES = {
     "mdhip_vm_eval_reduce_cols": [_P(VmProgram), C.c_int, _P(ArrayDesc), _P(ArrayDesc)],
     "mdhip_vm_jit_probe_multi": [_P(VmProgram), C.c_int, C.c_char_p, C.c_size_t],
     "mdhip_comm_probe": [],
+    "mdhip_comm_count": [_P(C.c_int)],
     "mdhip_comm_get_unique_id": [_P(C.c_uint8)],
     "mdhip_comm_init": [C.c_int, C.c_int, _P(C.c_uint8)],
     "mdhip_comm_allreduce_sum": [C.c_void_p, C.c_size_t, C.c_int],

@@ -388,11 +388,8 @@ template <class T> static bool fast_operand(const MdIter &it, int k, const mdhip
 
 // non-temporal streaming when one launch touches more than the Infinity Cache can hold
 static int nt_for(int64_t bytes) {
-  static int mode = [] {
-    const char *e = getenv("MDHIP_NT");  // 0 = never, 1 = always, unset = by size
-    return e ? (e[0] == '0' ? 0 : 1) : -1;
-  }();
-  if (mode >= 0) return mode;
+  const int mode = (int)md_opt(MD_OPT_NT);  // 0 = never, 1 = always, -1 = by size
+  if (mode >= 0) return mode != 0;
   return bytes > ((int64_t)320 << 20);
 }
 

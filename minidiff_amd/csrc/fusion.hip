@@ -490,7 +490,7 @@ static bool uncollapse_2d(const MdVmIter &it, int n_leaves, MdVmDev *D, int64_t 
 // interleaved row bands, one block per CU, <= 64 bands (the last block of a strip holds its partial rows in registers).
 static bool sweep_geometry(int64_t n_out, int64_t n_red, int ru, int64_t *NS, int64_t *NB) {
   if ((n_out & 3) || n_out < 4 || n_red < 512) return false;
-  static const int nb_force = [] { const char *e = getenv("MDHIP_SWEEP_NB"); return e ? atoi(e) : 0; }();
+  const int nb_force = (int)md_opt(MD_OPT_SWEEP_NB);
   const int64_t ns = (n_out + 255) / 256;
   int64_t nb = nb_force > 0 ? nb_force : (ns >= MD_NUM_CUS ? 1 : MD_NUM_CUS / ns);
   if (nb > 64) nb = 64;
@@ -521,7 +521,7 @@ static bool sweep_cols(const mdhip_vm_program *pr, int rop, const MdVmDev &D, in
   int64_t row_bytes = 0;
   for (int l = 0; l < pr->n_leaves; ++l)
     if (S.leaf_mode[l] == jit::LM_VEC) row_bytes += 4 * (int64_t)md_dtype_size(pr->leaves[l].dtype);
-  static const int ru_env = [] { const char *e = getenv("MDHIP_SWEEP_RU"); return e ? atoi(e) : 0; }();
+  const int ru_env = (int)md_opt(MD_OPT_SWEEP_RU);
   S.RU = ru_env > 0 ? ru_env : (row_bytes > 0 ? (int)((128 + row_bytes - 1) / row_bytes) : 1);
   if (S.RU > 8) S.RU = 8;
   if (S.RU < 1) S.RU = 1;
@@ -530,8 +530,8 @@ static bool sweep_cols(const mdhip_vm_program *pr, int rop, const MdVmDev &D, in
   S.nt = bytes > ((int64_t)320 << 20);
   // the evaluated value of a one-pass eval + column reduce is a large write next to (often much smaller) reads, and its
   // reader is whatever needed it in memory (cfg4: the weight-gradient GEMM, which is not bandwidth-bound): written around
-  // the caches the pass ran 32.9 -> 26.3 us on the cfg4 shape (128 MiB out, 32 MiB mask in), the GEMM behind it unchanged; MDHIP_SWEEP_NT_STORE=0 disables
-  static const int nt_store = [] { const char *e = getenv("MDHIP_SWEEP_NT_STORE"); return e ? atoi(e) : 1; }();
+  // the caches the pass ran 32.9 -> 26.3 us on the cfg4 shape (128 MiB out, 32 MiB mask in), the GEMM behind it unchanged (option sweep_nt_store = 0 disables)
+  const int nt_store = (int)md_opt(MD_OPT_SWEEP_NT_STORE);
   S.nt_store = nt_store && eval_out != nullptr && rows * inner * (int64_t)sizeof(T) >= ((int64_t)64 << 20);
   hipFunction_t fn = jit::get(S);
   if (!fn) return false;

@@ -1039,12 +1039,11 @@ static const float *md_zero_block() {
 // Three LDS buffers (DMA two k-tiles ahead, counted vmcnt at the k-tile boundary) for the 128-row direct-to-LDS tiles: when the grid
 // gives a CU one block at most — the third buffer's 32 KiB cost nothing then, and such grids (2048^3, the 1024-row shards of an 8-rank
 // cfg4, the all-reduce panels) are the ones whose k-tile (1.7 us) is about one DMA round trip: 2048^3 NN 132.9 -> 139.0, NT 132.7 ->
-// 140.1 TFLOP/s (profiles/r3_gemm_nbuf_ab.log). Larger grids keep two buffers and two blocks per CU. MDHIP_GEMM_NBUF=2 / 3 forces
-// (read at every launch: A/B runs, exactness tests).
+// 140.1 TFLOP/s (profiles/r3_gemm_nbuf_ab.log). Larger grids keep two buffers and two blocks per CU. option gemm_nbuf = 2 / 3 forces
+// (A/B runs, exactness tests).
 static bool md_gemm_nbuf3(int64_t blocks, int64_t K, int bk) {
   if (K < 2 * bk) return false;
-  const char *e = getenv("MDHIP_GEMM_NBUF");
-  if (e) return atoi(e) == 3;
+  if (const int64_t f = md_opt(MD_OPT_GEMM_NBUF)) return f == 3;
   return blocks <= MD_NUM_CUS;
 }
 
@@ -1089,7 +1088,7 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
   ga.tiles_n = (int)((ga.N + BN - 1) / BN);
   ga.vec_ok = edge ? 0 : 1;  // `edge` on entry = operands not 16-B aligned
   {
-    static const int sh = [] { const char *e = getenv("MDHIP_GEMM_SUPER"); return e ? atoi(e) : 8; }();
+    const int sh = (int)md_opt(MD_OPT_GEMM_SUPER);
     ga.super_h = (sh > 1 && ga.tiles_m >= sh && ga.tiles_n >= 8) ? sh : 0;
   }
   const bool aligned = !edge;   // (on entry `edge` only says whether the operands are 16-B aligned)
@@ -1104,7 +1103,7 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
   // 64 x 4096 batch through a 4096 x 4096 layer) is widened along k; >= 512 k per split
   const int64_t tiles = (int64_t)ga.tiles_m * ga.tiles_n * batch;
   int64_t splits = 1;
-  static const int splitk_mode = [] { const char *e = getenv("MDHIP_GEMM_SPLITK"); return e ? atoi(e) : 1; }();
+  const int splitk_mode = (int)md_opt(MD_OPT_GEMM_SPLITK);
   if (splitk_mode && BM == 64 && BN == 64 && tiles < MD_NUM_CUS && ga.K >= 1024) {  // (pick_cfg sends such shapes to 64x64)
     splits = (2 * MD_NUM_CUS + tiles - 1) / tiles;
     if (splits > ga.K / 512) splits = ga.K / 512;
@@ -1130,7 +1129,7 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
       else k_gemm_f32_mfma<BM, BN, BK, WM, WN, A_KC, B_KC, false, true><<<grid, 64 * WM * WN, 0, md_stream()>>>(ga);
     }
   }
-  static const bool stamp = [] { const char *e = getenv("MDHIP_GEMM_STAMP"); return e && atoi(e) == 1; }();
+  const bool stamp = md_opt(MD_OPT_GEMM_STAMP) == 1;
   if (stamp && splits == 1 && !edge && (size_t)grid.x * grid.z <= StampDump::kMax) {
     ga.stamp = StampDump::get().buffer();   // persistent: no sync behind the launch, the LAST launch's stamps are printed at exit
     StampDump::get().note(BM, BN, BK, (size_t)grid.x * grid.z);
@@ -1139,8 +1138,7 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
     bool ragged_dma = false;
     if constexpr (!A_KC && !B_KC && SCHED != 0 && BK >= 32) {
       // ragged TN: still direct to LDS when every 16-B piece lies wholly inside or outside the operands (M, N multiples of 4)
-      const char *e = getenv("MDHIP_GEMM_GLDS");
-      ragged_dma = edge && aligned && (e ? atoi(e) != 0 : true) && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp && (ga.M % 4 == 0 || ga.pad_m) && (ga.N % 4 == 0 || ga.pad_n) && ga.a_ks > 0 && ga.b_ks > 0 &&
+      ragged_dma = edge && aligned && md_opt(MD_OPT_GEMM_GLDS) != 0 && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp && (ga.M % 4 == 0 || ga.pad_m) && (ga.N % 4 == 0 || ga.pad_n) && ga.a_ks > 0 && ga.b_ks > 0 &&
                    (ga.zero = md_zero_block()) != nullptr;
       if (ragged_dma) {
         // whole k-tiles on the 128-row tiles: predicated lanes + scalar-base addresses (4100 x 4096 x 4100: 104-108 -> 112-124 TFLOP/s);
@@ -1156,12 +1154,11 @@ static int launch_cfg(GemmArgs ga, int64_t batch, bool edge) {
     else {
       bool glds = false;
       if constexpr (!A_KC && !B_KC && SCHED != 0 && BK >= 32) {
-        // TN with whole aligned tiles and 32-deep k-tiles: both operands go direct to LDS (MDHIP_GEMM_GLDS=0, read at every
-        // launch, keeps the register-staged kernel: A/B runs). Same-box A/B, profiles/r2_gemm_glds_ab.log: 256x256x32 at
+        // TN with whole aligned tiles and 32-deep k-tiles: both operands go direct to LDS (option gemm_glds = 0 keeps the
+        // register-staged kernel: A/B runs). Same-box A/B, profiles/r2_gemm_glds_ab.log: 256x256x32 at
         // 4096^3 140.1 -> 141.9 TFLOP/s, the 8-wave 128x128x32 at 2048^3 119.0 -> 127.8; the 16-deep 256x128 tile LOSES
         // (135.7 -> 130.8: its k-tile is too short for a one-tile-ahead DMA) and keeps its registers.
-        const char *e = getenv("MDHIP_GEMM_GLDS");
-        glds = (e ? atoi(e) != 0 : true) && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp && ga.a_ks > 0 && ga.b_ks > 0 && ga.a_ks < (1ll << 26) && ga.b_ks < (1ll << 26);   // (32-bit lane offsets)
+        glds = md_opt(MD_OPT_GEMM_GLDS) != 0 && ga.a_ms == 1 && ga.b_ns == 1 && !ga.stamp && ga.a_ks > 0 && ga.b_ks > 0 && ga.a_ks < (1ll << 26) && ga.b_ks < (1ll << 26);   // (32-bit lane offsets)
         if (glds) {
           if constexpr (3 * (BM + BN) * BK * 4 <= 128 * 1024) {
             if (md_gemm_nbuf3((int64_t)grid.x * grid.z, ga.K, BK)) {
@@ -1191,9 +1188,9 @@ enum { CFG_128x128x16 = 0, CFG_64x64x16, CFG_128x64x16, CFG_256x128x16, CFG_256x
 // `est` (optional): the model's time for the chosen tile, in units of 512 K / 1e12 seconds (rounds x BM x BN / TFLOP/s)
 static int pick_cfg(const GemmArgs &ga, int64_t batch, bool vector_staged, bool dma_ok = false, double *est = nullptr) {
   if (est) *est = 64.0 * 64.0 / 120.0;   // (the early returns: one round of the small tile, split-K or not)
-  if (const char *e = getenv("MDHIP_GEMM_CFG")) {  // experiments only
-    int v = atoi(e);
-    if (v >= 0 && v < CFG_COUNT) return v;
+  {  // experiments / exactness tests only (option gemm_cfg)
+    const int64_t v = md_opt(MD_OPT_GEMM_CFG);
+    if (v >= 0 && v < CFG_COUNT) return (int)v;
   }
   // Cost model over the production tiles: a CU works through ceil(tiles / CUs) tiles of BM*BN outputs at the rate measured
   // for that tile on full grids (profiles/r1_gemm_tile_ab.log, r2_gemm_small_grid_ab.log, r2_gemm_glds_ab.log) — big tiles
@@ -1242,10 +1239,10 @@ static int launch_kc_glds(GemmArgs ga, int64_t batch, bool edge) {
   }
   ga.tiles_m = (int)((ga.M + BM - 1) / BM);
   ga.tiles_n = (int)((ga.N + BN - 1) / BN);
-  static const int sh = [] { const char *e = getenv("MDHIP_GEMM_SUPER"); return e ? atoi(e) : 8; }();
+  const int sh = (int)md_opt(MD_OPT_GEMM_SUPER);
   ga.super_h = (sh > 1 && ga.tiles_m >= sh && ga.tiles_n >= 8) ? sh : 0;
   dim3 grid((unsigned)(ga.tiles_m * ga.tiles_n), 1, (unsigned)batch);
-  static const bool stamp = [] { const char *e = getenv("MDHIP_GEMM_STAMP"); return e && atoi(e) == 1; }();
+  const bool stamp = md_opt(MD_OPT_GEMM_STAMP) == 1;
   if (stamp && (size_t)grid.x * grid.z <= StampDump::kMax) {
     ga.stamp = StampDump::get().buffer();
     StampDump::get().note(BM, BN, BK, (size_t)grid.x * grid.z);
@@ -1281,10 +1278,9 @@ static int launch_kc_glds(GemmArgs ga, int64_t batch, bool edge) {
 
 template <bool A_KC, bool B_KC>
 static bool md_gemm_dma_ok(const GemmArgs &ga, bool edge) {
-  // direct-to-LDS kernels: aligned operands whose vector axis has stride 1 (MDHIP_GEMM_GLDS=0, read at every launch, keeps
+  // direct-to-LDS kernels: aligned operands whose vector axis has stride 1 (option gemm_glds = 0 keeps
   // the register-staged kernels: A/B runs and tests)
-  const char *e = getenv("MDHIP_GEMM_GLDS");
-  return (e ? atoi(e) != 0 : true) && !edge && !ga.stamp && (A_KC ? ga.a_ks == 1 : ga.a_ms == 1) && (B_KC ? ga.b_ks == 1 : ga.b_ns == 1) &&
+  return md_opt(MD_OPT_GEMM_GLDS) != 0 && !edge && !ga.stamp && (A_KC ? ga.a_ks == 1 : ga.a_ms == 1) && (B_KC ? ga.b_ks == 1 : ga.b_ns == 1) &&
          (A_KC || !B_KC) &&   // (A row-contiguous with B k-contiguous — "TT" — has no such kernel: HipExec::gemm swaps it into NN)
          // sizes the tiles do not divide: every 16-B piece must lie wholly inside or outside its operand
          ((A_KC || B_KC) ? ga.K % 4 == 0 : true) && (A_KC || ga.M % 4 == 0 || ga.pad_m) && (B_KC || ga.N % 4 == 0 || ga.pad_n);
@@ -1338,8 +1334,7 @@ static int launch_mfma(const GemmArgs &ga, int64_t batch, bool edge) {
 // on one stream writing disjoint parts of C. Chosen by the same cost model as the tiles, when it beats the single launch by > 3 %.
 template <bool A_KC, bool B_KC>
 static int launch_mfma_peeled(const GemmArgs &ga, int64_t batch, bool edge) {
-  const char *pe = getenv("MDHIP_GEMM_PEEL");   // (read at every launch: A/B runs and the exactness tests)
-  const int mode = pe ? atoi(pe) : 1;           // 0 never, 1 by the model, 2 whenever there is an edge to peel
+  const int mode = (int)md_opt(MD_OPT_GEMM_PEEL);   // 0 never, 1 by the model, 2 whenever there is an edge to peel
   const int64_t G = 256;
   const int64_t Mm = ga.M / G * G, Nm = ga.N / G * G, Mr = ga.M - Mm, Nr = ga.N - Nm;
   if (mode == 0 || edge || ga.stamp || (Mr == 0 && Nr == 0) || Mm == 0 || Nm == 0 || ga.K % 32 || ga.bias) return launch_mfma<A_KC, B_KC>(ga, batch, edge);
@@ -1674,9 +1669,8 @@ template <bool A_KC, bool B_KC>
 static int launch_f64_pick(const GemmArgs64 &ga, int64_t batch, bool edge) {
   const int64_t t128 = ((ga.M + 127) / 128) * ((ga.N + 127) / 128) * batch;
   if constexpr (!A_KC && !B_KC) {   // TN: both operands row-contiguous -> direct to LDS (k_gemm_f64_tn_glds)
-    const char *e = getenv("MDHIP_GEMM_GLDS");   // (read at every launch: A/B runs and the exactness tests)
     const int64_t lim = 1ll << 25;
-    if ((e ? atoi(e) != 0 : true) && !edge && ga.a_ms == 1 && ga.b_ns == 1 && ga.M % 128 == 0 && ga.N % 128 == 0 && ga.K % 16 == 0 && ga.K >= 32 &&
+    if (md_opt(MD_OPT_GEMM_GLDS) != 0 && !edge && ga.a_ms == 1 && ga.b_ns == 1 && ga.M % 128 == 0 && ga.N % 128 == 0 && ga.K % 16 == 0 && ga.K >= 32 &&
         t128 >= MD_NUM_CUS && ga.a_ks > 0 && ga.b_ks > 0 && ga.a_ks < lim && ga.b_ks < lim) {
       GemmArgs64 g2 = ga;
       g2.tiles_m = (int)(ga.M / 128);
@@ -1705,8 +1699,7 @@ struct HipExec {
       // product of the two STORAGES (B' = N x K k-contiguous, A' = K x M row-contiguous), so it runs on the NN direct-to-LDS
       // kernels with the operands swapped and C addressed through swapped strides; the epilogue then holds four consecutive
       // elements of a C row per lane and stores them as one 16-B vector (c_vec_rows)
-      const char *tt_env = getenv("MDHIP_GEMM_TT_SWAP");   // (read at every launch: A/B runs and the exactness tests)
-      if (!(tt_env && tt_env[0] == '0') && g.a_ms == 1 && g.a_ks != 1 && g.b_ks == 1 && g.b_ns != 1 && g.M > 1 && g.N > 1 && g.K > 1) {
+      if (md_opt(MD_OPT_GEMM_TT_SWAP) != 0 && g.a_ms == 1 && g.a_ks != 1 && g.b_ks == 1 && g.b_ns != 1 && g.M > 1 && g.N > 1 && g.K > 1) {
         g.a = g_in.b; g.b = g_in.a;
         g.M = g_in.N; g.N = g_in.M;
         g.a_bs = g_in.b_bs; g.a_ms = g_in.b_ns; g.a_ks = g_in.b_ks;
@@ -1738,7 +1731,7 @@ struct HipExec {
         // then the direct-to-LDS kernels — 4097 x 4096 x 4100 TN ran at 71 TFLOP/s on the register-staged edge kernel
         // (DESIGN §9.1). Worth it when the product is >= 50x the copy (2 M N K flop against 8 bytes per copied element).
         void *tmp_a = nullptr, *tmp_b = nullptr;
-        static const bool repack_on = [] { const char *e = getenv("MDHIP_GEMM_REPACK"); return !(e && e[0] == '0'); }();
+        const bool repack_on = md_opt(MD_OPT_GEMM_REPACK) != 0;
         if (edge && repack_on && g.batch == 1 && (A_KC || B_KC ? g.K % 4 == 0 : true) && g.M >= 256 && g.N >= 256 && g.K >= 256 && !ga.stamp) {
           const bool a_bad = !al16(g.a) || ((A_KC ? g.a_ms : g.a_ks) & 3), b_bad = !al16(g.b) || ((B_KC ? g.b_ns : g.b_ks) & 3);
           auto repack = [](const float *src, int64_t rows, int64_t cols, int64_t row_stride, void **tmp, int64_t *ld) -> int {
@@ -1788,7 +1781,7 @@ struct HipExec {
     if constexpr (md_same<T, double>::value) {
       const bool a_kc = g.a_ks == 1 || g.K == 1, a_mc = g.a_ms == 1 || g.M == 1;
       const bool b_kc = g.b_ks == 1 || g.K == 1, b_nc = g.b_ns == 1 || g.N == 1;
-      static const int f64_mfma = [] { const char *e = getenv("MDHIP_GEMM_F64_MFMA"); return e ? atoi(e) : 1; }();
+      const int f64_mfma = (int)md_opt(MD_OPT_GEMM_F64_MFMA);
       if (f64_mfma && g.M * g.N >= 64 * 64 && g.K >= 8 && (a_kc || a_mc) && (b_kc || b_nc) && g.M * g.N < (1ll << 40)) {
         GemmArgs64 ga;
         ga.A = (const double *)g.a; ga.B = (const double *)g.b; ga.C = (double *)g.c;
@@ -1873,8 +1866,7 @@ extern "C" int mdhip_matmul_bias_relu_sum(const mdhip_array *a, const mdhip_arra
   ga.partial = (float *)sum_out->data;
   // the plain kernel's tile choice (and with it the plain product's summation order: a mask recomputed from `a @ b + bias`
   // agrees bit for bit), restricted to the tiles that divide the problem
-  const char *e = getenv("MDHIP_GEMM_GLDS");
-  const bool dma_ok = (e ? atoi(e) != 0 : true) && K % 32 == 0;
+  const bool dma_ok = md_opt(MD_OPT_GEMM_GLDS) != 0 && K % 32 == 0;
   const int cfg = pick_cfg(ga, 1, false, dma_ok);
   if (dma_ok) {
     if (cfg == CFG_256x256x32 && M % 256 == 0 && N % 256 == 0) return launch_epi<256, 256, 2, 2, true>(ga);

@@ -728,7 +728,7 @@ int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const m
   if (runs) {
     const int vshift = V == 16 ? 4 : V == 4 ? 2 : 1;
     const int64_t run_elems = pl->shape[nd - 1], n_runs = total / run_elems;
-    static const bool runs_on = [] { const char *e = getenv("MDHIP_GATHER_RUNS"); return !(e && e[0] == '0'); }();   // 0: per-unit plan arithmetic (A/B)
+    const bool runs_on = md_opt(MD_OPT_GATHER_RUNS) != 0;   // 0: per-unit plan arithmetic (A/B)
     if (runs_on && run_elems / V >= 64 && n_runs >= 64) {
       // a wave per run, up to 16 waves per CU resident (64 KiB of loads in flight per CU)
       int64_t blocks = (n_runs + 3) / 4;
@@ -772,7 +772,7 @@ int mdhip_scatter(const mdhip_index_plan *pl, void *dst, int dtype, const mdhip_
       int64_t lo, hi;
       run_key_range(pl, L, &lo, &hi);
       const int64_t nkeys = (hi - lo) / unit + 1;
-      static const bool census_on = [] { const char *e = getenv("MDHIP_SCATTER_CENSUS"); return !(e && e[0] == '0'); }();   // 0: always sort (A/B)
+      const bool census_on = md_opt(MD_OPT_SCATTER_CENSUS) != 0;   // 0: always sort (A/B)
       if (census_on && total > 4096 && nkeys > 0 && nkeys <= (1ll << 22) && mdhip_alloc((size_t)nkeys * sizeof(int), &census) == MDHIP_OK) {
         (void)hipMemsetAsync(census, 0, (size_t)nkeys * sizeof(int), md_stream());
         k_check_bounds_dups<<<md_grid_for(P), MD_BLOCK, 0, md_stream()>>>(*pl, P, L, lo, unit, (int *)census, (int *)flag);

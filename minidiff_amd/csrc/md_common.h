@@ -10,6 +10,7 @@
 
 #include "../../include/mdhip.h"
 #include "md_ops.h"
+#include "md_options.h"
 
 // ---- errors ------------------------------------------------------------------
 std::string &md_err_slot();  // thread-local storage lives in the runtime TU

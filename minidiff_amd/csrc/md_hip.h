@@ -31,12 +31,8 @@ int md_hip_check(hipError_t e, const char *what);
 constexpr int MD_NUM_CUS = 256;
 constexpr int MD_BLOCK = 256;
 static inline int md_max_blocks() {
-  static int v = [] {
-    const char *e = getenv("MDHIP_MAX_BLOCKS");  // tuning knob for experiments
-    int n = e ? atoi(e) : 0;
-    return n > 0 ? n : MD_NUM_CUS * 8;
-  }();
-  return v;
+  const int n = (int)md_opt(MD_OPT_MAX_BLOCKS);  // experiment knob (md_options.h)
+  return n > 0 ? n : MD_NUM_CUS * 8;
 }
 static inline int md_grid_for(int64_t work_items, int per_block = MD_BLOCK, int max_blocks = 0) {
   if (max_blocks <= 0) max_blocks = md_max_blocks();

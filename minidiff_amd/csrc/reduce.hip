@@ -894,7 +894,7 @@ struct HipExec {
     if constexpr (sizeof(Tacc) >= 4) {
       // many short contiguous rows: a wave per output (every row must start on a 16-B boundary)
       constexpr int V = 16 / sizeof(Tacc);
-      static const bool wave_on = [] { const char *e = getenv("MDHIP_ROWS_WAVE"); return !(e && e[0] == '0'); }();   // 0: block per output (A/B)
+      const bool wave_on = md_opt(MD_OPT_ROWS_WAVE) != 0;   // 0: block per output (A/B)
       bool aligned = ((uintptr_t)x->data & 15) == 0;
       for (int k = 0; k < pl.nk; ++k) aligned = aligned && (pl.kx[k] % V) == 0;
       if (wave_on && pl.nr == 1 && pl.rx[0] == 1 && x->dtype == md_dtype_of<Tacc>::value && aligned && n_red >= 32 && n_red <= 64 * V * 8 &&
@@ -915,8 +915,8 @@ struct HipExec {
         const bool vec_ok = pl.nk == 1 && pl.nr == 1 && pl.ko[0] == 1 && x->dtype == md_dtype_of<Tacc>::value &&
                             (n_out % V) == 0 && (pl.rx[0] % V) == 0 && ((uintptr_t)x->data & 15) == 0 &&
                             ((uintptr_t)out->data & 15) == 0 && n_red >= 16;
-        static const int sweep_mode = [] { const char *e = getenv("MDHIP_COLS_SWEEP"); return e ? atoi(e) : 1; }();  // 0: the tiled kernel below (A/B)
-        static const int nb_force = [] { const char *e = getenv("MDHIP_COLS_NB"); return e ? atoi(e) : 0; }();
+        const int sweep_mode = (int)md_opt(MD_OPT_COLS_SWEEP);  // 0: the tiled kernel below (A/B)
+        const int nb_force = (int)md_opt(MD_OPT_COLS_NB);
         // (f64 / integer max and min keep the tiled kernel — their compare chain wants more waves per CU)
         constexpr bool cheap = md_same<R, RSum>::value || md_same<R, RProd>::value ||
                                ((md_same<R, RMax>::value || md_same<R, RMin>::value) && md_same<Tacc, float>::value);
@@ -1008,8 +1008,8 @@ struct HipExec {
       return rc;
     }
     if (rows_ok) {
-      // ~1024 blocks in total (4 per CU; MDHIP_ROWS_BLOCKS overrides: experiments); each block should still see >= 4096 items
-      static const int64_t total_blocks = [] { const char *e = getenv("MDHIP_ROWS_BLOCKS"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 1024); }();
+      // ~1024 blocks in total (4 per CU; option rows_blocks overrides: experiments); each block should still see >= 4096 items
+      const int64_t total_blocks = md_opt(MD_OPT_ROWS_BLOCKS) > 0 ? md_opt(MD_OPT_ROWS_BLOCKS) : 1024;
       int64_t splits = total_blocks / n_out;
       const int64_t max_splits = ceil_div(n_red, 4096);
       if (splits > max_splits) splits = max_splits;
@@ -1023,7 +1023,7 @@ struct HipExec {
       const bool nt = n_red * n_out * (int64_t)sizeof(Tacc) > ((int64_t)320 << 20);
       int rc;
       if constexpr (sizeof(Tacc) >= 4) {
-        static const bool all_on = [] { const char *e = getenv("MDHIP_REDUCE_ALL"); return !(e && e[0] == '0'); }();  // 0: the general rows kernel (A/B)
+        const bool all_on = md_opt(MD_OPT_REDUCE_ALL) != 0;  // 0: the general rows kernel (A/B)
         if (all_on && n_out == 1 && pl.nr == 1 && pl.rx[0] == 1 && x->dtype == md_dtype_of<Tacc>::value && ((uintptr_t)x->data & 15) == 0) {
           if (nt) MD_LAUNCH((k_reduce_all<R, Tacc, To, true>), (unsigned)splits, MD_BLOCK, (const Tacc *)x->data, n_red, (Tacc *)partial, md_tickets(), (To *)out->data);
           else MD_LAUNCH((k_reduce_all<R, Tacc, To, false>), (unsigned)splits, MD_BLOCK, (const Tacc *)x->data, n_red, (Tacc *)partial, md_tickets(), (To *)out->data);
@@ -1031,7 +1031,7 @@ struct HipExec {
           mdhip_free(partial);
           return rc;
         }
-        static const bool ticket_on = [] { const char *e = getenv("MDHIP_ROWS_TICKET"); return !(e && e[0] == '0'); }();  // 0: two launches (A/B)
+        const bool ticket_on = md_opt(MD_OPT_ROWS_TICKET) != 0;  // 0: two launches (A/B)
         if (ticket_on && n_out * (splits >= 64 ? MD_TICKET2_WORDS : MD_TICKET_PAD) <= MD_TICKET_WORDS) {
           if (nt) MD_LAUNCH((k_reduce_rows<R, Tacc, To, 2, true>), (unsigned)(n_out * splits), MD_BLOCK, pl, x->data, x->dtype, splits, (To *)out->data, (Tacc *)partial, md_tickets());
           else MD_LAUNCH((k_reduce_rows<R, Tacc, To, 2>), (unsigned)(n_out * splits), MD_BLOCK, pl, x->data, x->dtype, splits, (To *)out->data, (Tacc *)partial, md_tickets());
@@ -1062,10 +1062,10 @@ struct HipExec {
           (pl.rx[0] % V) == 0 && ((uintptr_t)x->data & 15) == 0 && pl.n_red >= 16) {
         const int64_t n_out = pl.n_out, n_red = pl.n_red;
         const int64_t bxv = ceil_div(n_out, 64 * V);
-        static const bool strips_on = [] { const char *e = getenv("MDHIP_ARG_STRIPS"); return !(e && e[0] == '0'); }();   // 0: the chunked kernel + finish pass (A/B)
+        const bool strips_on = md_opt(MD_OPT_ARG_STRIPS) != 0;   // 0: the chunked kernel + finish pass (A/B)
         if (strips_on && n_red < (1ll << 31) && n_red >= 64 && bxv * MD_TICKET_PAD <= MD_TICKET_WORDS) {
           const int64_t NS = bxv;
-          static const int arg_blocks = [] { const char *e = getenv("MDHIP_ARG_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : MD_NUM_CUS; }();   // one block per CU, as the column sums (rocprofv3: 26.6 us against 38.0 with four per CU); the knob is for experiments
+          const int arg_blocks = md_opt(MD_OPT_ARG_BLOCKS) > 0 ? (int)md_opt(MD_OPT_ARG_BLOCKS) : MD_NUM_CUS;   // one block per CU, as the column sums (rocprofv3: 26.6 us against 38.0 with four per CU); the knob is for experiments
           int64_t NB = ceil_div(arg_blocks, NS);
           if (NB > 64) NB = 64;
           if (NB > n_red / 32) NB = n_red / 32;

@@ -104,11 +104,50 @@ int mdhip_init(int device) {
   MD_TRY(md_hip_check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties"));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return md_fail(MDHIP_ERUNTIME, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+  (void)md_opt_table();  // the environment is read here, once (md_options.h); launch paths never call getenv
   // counters of the single-launch split reductions (md_ticket.h): zero now, and zero again after every launch that uses them
   MD_TRY(md_hip_check(hipMalloc((void **)&s.tickets, MD_TICKET_WORDS * sizeof(unsigned)), "hipMalloc(tickets)"));
-  MD_TRY(md_hip_check(hipMemset(s.tickets, 0, MD_TICKET_WORDS * sizeof(unsigned)), "hipMemset(tickets)"));
-  MD_TRY(md_hip_check(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate"));
+  int rc = md_hip_check(hipMemset(s.tickets, 0, MD_TICKET_WORDS * sizeof(unsigned)), "hipMemset(tickets)");
+  if (rc == MDHIP_OK) rc = md_hip_check(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate");
+  if (rc != MDHIP_OK) {  // nothing half-initialised stays behind
+    (void)hipFree(s.tickets);
+    s.tickets = nullptr;
+    s.stream = nullptr;
+    return rc;
+  }
   s.device = device;
+  return MDHIP_OK;
+}
+
+// Undo mdhip_init: the stream, the ticket block and every cached block go back to the driver. Refused while device blocks
+// are still live (their owners would free them into a dead allocator). After it, mdhip_init may bind again.
+int mdhip_shutdown(void) {
+  State &s = S();
+  std::lock_guard<std::mutex> lk(s.mu);
+  if (!s.stream) return MDHIP_OK;
+  if (s.capturing) return md_fail(MDHIP_ERUNTIME, "shutdown: a graph capture is in progress");
+  if (!s.live.empty()) return md_fail(MDHIP_ERUNTIME, "shutdown: %zu device blocks are still live", s.live.size());
+  (void)hipStreamSynchronize(s.stream);
+  release_cache_locked(s);
+  (void)hipFree(s.tickets);
+  s.tickets = nullptr;
+  (void)hipStreamDestroy(s.stream);
+  s.stream = nullptr;
+  s.device = -1;
+  return MDHIP_OK;
+}
+
+// Test hook + A/B scripts: set / read one entry of the option table (md_options.h) by name; effective from the next launch.
+int mdhip_debug_set_option(const char *name, int64_t value) {
+  const int id = name ? md_opt_find(name) : -1;
+  if (id < 0) return md_fail(MDHIP_EVALUE, "unknown option %s", name ? name : "(null)");
+  md_opt_table()[id] = value;
+  return MDHIP_OK;
+}
+int mdhip_debug_get_option(const char *name, int64_t *value_out) {
+  const int id = name ? md_opt_find(name) : -1;
+  if (id < 0 || !value_out) return md_fail(MDHIP_EVALUE, "unknown option %s", name ? name : "(null)");
+  *value_out = md_opt_table()[id];
   return MDHIP_OK;
 }
 
@@ -219,13 +258,7 @@ HostPool &HP() {
   static HostPool h;
   return h;
 }
-int64_t pinned_cap() {
-  static int64_t v = [] {
-    const char *e = getenv("MDHIP_PINNED_CAP");
-    return e ? (int64_t)atoll(e) : ((int64_t)4 << 30);
-  }();
-  return v;
-}
+int64_t pinned_cap() { return md_opt(MD_OPT_PINNED_CAP); }
 }  // namespace
 
 extern "C" {
@@ -290,8 +323,11 @@ int mdhip_d2d(void *dst, const void *src, size_t n) {
 }
 int mdhip_sync(void) {
   if (!S().stream) return MDHIP_OK;
-  MD_TRY(md_hip_check(hipStreamSynchronize(md_stream()), "hipStreamSynchronize"));
-  return md_hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  int rc = md_hip_check(hipStreamSynchronize(md_stream()), "hipStreamSynchronize");
+  if (rc == MDHIP_OK) rc = md_hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  // a kernel that died mid-way may have left a count behind: the next split reduction must start from zero
+  if (rc != MDHIP_OK) (void)hipMemsetAsync(S().tickets, 0, MD_TICKET_WORDS * sizeof(unsigned), md_stream());
+  return rc;
 }
 
 int mdhip_event_create(void **ev) {
@@ -364,6 +400,9 @@ int mdhip_graph_end(void **graph_out) {
         s.stream = fresh;
       }
     }
+    // the captured kernels never ran, so no ticket was taken; zeroing the counters all the same costs nothing and keeps a
+    // reduction after ANY failed capture from meeting a non-zero count (it would never elect a last block)
+    (void)hipMemsetAsync(s.tickets, 0, MD_TICKET_WORDS * sizeof(unsigned), s.stream);
     // abort: hand every reserved block back to the general pool
     for (auto it = s.owner.begin(); it != s.owner.end();) {
       if (it->second == g) it = s.owner.erase(it); else ++it;
@@ -416,6 +455,7 @@ static struct {
   int (*CommInitRank)(md_ncclComm_t *, int, md_ncclUniqueId, int) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, md_ncclComm_t, hipStream_t) = nullptr;
   int (*CommDestroy)(md_ncclComm_t) = nullptr;
+  int (*CommCount)(md_ncclComm_t, int *) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
   md_ncclComm_t comm = nullptr;
   int nranks = 0;
@@ -454,6 +494,7 @@ static int rccl_load() {
   R.CommInitRank = (decltype(R.CommInitRank))dlsym(R.h, "ncclCommInitRank");
   R.AllReduce = (decltype(R.AllReduce))dlsym(R.h, "ncclAllReduce");
   R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.h, "ncclCommDestroy");
+  R.CommCount = (decltype(R.CommCount))dlsym(R.h, "ncclCommCount");
   R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.h, "ncclGetErrorString");
   if (!R.GetUniqueId || !R.CommInitRank || !R.AllReduce || !R.CommDestroy)
     return md_fail(MDHIP_ERUNTIME, "librccl is missing an expected symbol");
@@ -509,8 +550,7 @@ int mdhip_comm_allreduce_sum_async(void *buf, size_t count, int dtype) {
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // "hi" is the numerically smallest value
     // normal priority unless asked: on this part the mere existence of a high-priority queue slows
     // the compute queue's GEMMs by ~7 % (measured, 4096^3), more than a late collective start costs
-    const char *pe = getenv("MDHIP_COMM_PRIORITY");
-    if (!(pe && atoi(pe) == 1)) hi = 0;
+    if (md_opt(MD_OPT_COMM_PRIORITY) != 1) hi = 0;
     MD_TRY(md_hip_check(hipStreamCreateWithPriority(&R.cstream, hipStreamNonBlocking, hi), "hipStreamCreateWithPriority"));
     MD_TRY(md_hip_check(hipEventCreateWithFlags(&R.ev_ready, hipEventDisableTiming), "hipEventCreate"));
     MD_TRY(md_hip_check(hipEventCreateWithFlags(&R.ev_done, hipEventDisableTiming), "hipEventCreate"));
@@ -534,6 +574,12 @@ int mdhip_comm_wait(void) {
   return md_hip_check(hipStreamWaitEvent(md_stream(), R.ev_done, 0), "hipStreamWaitEvent");
 }
 int mdhip_comm_probe(void) { return rccl_load(); }
+// ranks of the live communicator as RCCL itself reports them (ncclCommCount) — bench.py puts it in the line as `rccl_ranks`
+int mdhip_comm_count(int *nranks_out) {
+  if (!R.comm) return md_fail(MDHIP_ERUNTIME, "communicator not initialised");
+  if (!R.CommCount) return md_fail(MDHIP_ERUNTIME, "librccl has no ncclCommCount");
+  return rccl_check(R.CommCount(R.comm, nranks_out), "ncclCommCount");
+}
 int mdhip_comm_destroy(void) {
   if (!R.comm) return MDHIP_OK;
   if (R.cstream) {

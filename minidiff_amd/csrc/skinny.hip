@@ -343,8 +343,7 @@ template <class T> int skinny_run(const SkinnyArgs &a, int64_t batch, bool rowdo
 // -1: not a product for these kernels (the caller goes on to the MFMA / generic paths); otherwise the launch status.
 // dtype: MDHIP_F32 / MDHIP_F64.
 int md_gemm_skinny(const MdGemm &g, int dtype) {
-  static const bool on = [] { const char *e = getenv("MDHIP_GEMM_SKINNY"); return !(e && e[0] == '0'); }();
-  if (!on || (dtype != MDHIP_F32 && dtype != MDHIP_F64) || g.batch < 1 || g.batch > 65535) return -1;
+  if (!md_opt(MD_OPT_GEMM_SKINNY) || (dtype != MDHIP_F32 && dtype != MDHIP_F64) || g.batch < 1 || g.batch > 65535) return -1;
   const int64_t esz = dtype == MDHIP_F32 ? 4 : 8, V = 16 / esz;
   SkinnyArgs a{};
   if (g.N <= 8 && g.M > 8) {          // thin N: X = A, Y = B, out = C

@@ -99,6 +99,7 @@ class SegmentedSweep:
             raise RuntimeError("this build of the library cannot capture graphs")
         names = [n for n in ("allreduce_sum_async_", "allreduce_sum_", "wait") if hasattr(comm, n)]
         originals = {n: getattr(comm, n) for n in names}
+        was_instance_attr = {n: n in vars(comm) for n in names}   # (a caller may have patched the INSTANCE already: tests count calls that way)
 
         def cut(fn):
             def wrapped(*a):
@@ -125,8 +126,11 @@ class SegmentedSweep:
             self.close()
             raise
         finally:
-            for n in names:
-                delattr(comm, n)
+            for n in names:   # put back exactly what was there: an instance attribute is restored, a class method is uncovered
+                if was_instance_attr[n]:
+                    setattr(comm, n, originals[n])
+                else:
+                    delattr(comm, n)
         self.replays = 0
         self.segments = sum(1 for op in self._ops if op[0] == "graph")
         self.calls = sum(1 for op in self._ops if op[0] == "call")

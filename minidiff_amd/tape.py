@@ -23,6 +23,8 @@ baseline need the reference's arithmetic. The tape itself does no arithmetic.
 from __future__ import annotations
 
 import types
+
+import numpy as np
 from contextvars import ContextVar
 from math import prod as _pyprod
 
@@ -58,21 +60,36 @@ def _signature(root):
     per graph; every node is hashed once (graph.SweepCache keys captured hipGraphs by (structural hash, this))."""
     leaf_index, memo = {}, {}
 
+    def value_sig(x):
+        """A non-op-input value (a constant operand, a getitem key, a keyword argument). Array-likes are NEVER repr()-ed: the
+        repr of a device array is a device-to-host copy and a stream sync — one per such op in every backward(), and inside a
+        stream capture it makes the sweep uncapturable — and NumPy's repr elides the middle of a large array, so two index
+        arrays could collide. They are identified like leaves: type, shape, dtype and first-sighting index by identity."""
+        if hasattr(x, "op_node"):                     # a Tensor inside a key / kwarg (x[(idx_tensor, slice(None))])
+            if x.op_node is None or getattr(x, "is_leaf", False):
+                return ("L", leaf_index.setdefault(id(x), len(leaf_index)), tuple(x.shape), str(x.dtype))
+            return node_sig(x.op_node)
+        if isinstance(x, (tuple, list)):
+            return (type(x).__name__,) + tuple(value_sig(v) for v in x)
+        if isinstance(x, dict):
+            return ("dict",) + tuple((k, value_sig(v)) for k, v in sorted(x.items(), key=lambda kv: repr(kv[0])))
+        if isinstance(x, slice):
+            return ("slice", value_sig(x.start), value_sig(x.stop), value_sig(x.step))
+        if isinstance(x, np.ndarray) and x.size <= 64:    # a small HOST constant: by value (a replay bakes its upload in)
+            return ("H", tuple(x.shape), str(x.dtype), x.tobytes())
+        if hasattr(x, "shape") and hasattr(x, "dtype") and not isinstance(x, (np.generic,)):   # DeviceArray / large ndarray
+            return ("A", type(x).__name__, leaf_index.setdefault(id(x), len(leaf_index)), tuple(x.shape), str(x.dtype))
+        return ("C", type(x).__name__, repr(x))       # Python / NumPy scalars, None, Ellipsis, strings, dtypes
+
     def node_sig(node):
         got = memo.get(id(node))
         if got is not None:
             return ("R", got[1])                      # a shared intermediate: by its first-visit index
         index = len(memo)
         memo[id(node)] = (None, index)
-        parts = [node.name, tuple(sorted((k, repr(v)) for k, v in node.kwargs.items()))]
+        parts = [node.name, tuple(sorted((k, value_sig(v)) for k, v in node.kwargs.items()))]
         for x in node.inputs:
-            if hasattr(x, "op_node"):
-                if x.op_node is None or getattr(x, "is_leaf", False):
-                    parts.append(("L", leaf_index.setdefault(id(x), len(leaf_index)), tuple(x.shape), str(x.dtype)))
-                else:
-                    parts.append(node_sig(x.op_node))
-            else:
-                parts.append(("C", type(x).__name__, repr(x)))
+            parts.append(value_sig(x))
         h = hash(tuple(parts))
         memo[id(node)] = (h, index)
         return ("N", h)

@@ -132,6 +132,20 @@ extern "C" {
 
 int mdhip_init(int) { return MDHIP_OK; }
 int mdhip_device(int *d) { *d = -1; return MDHIP_OK; }
+int mdhip_shutdown(void) { return MDHIP_OK; }
+// the same option table as the product (csrc/md_options.h): the double's host logic reads it where the product's does
+int mdhip_debug_set_option(const char *name, int64_t value) {
+  const int id = name ? md_opt_find(name) : -1;
+  if (id < 0) return md_fail(MDHIP_EVALUE, "unknown option %s", name ? name : "(null)");
+  md_opt_table()[id] = value;
+  return MDHIP_OK;
+}
+int mdhip_debug_get_option(const char *name, int64_t *value_out) {
+  const int id = name ? md_opt_find(name) : -1;
+  if (id < 0 || !value_out) return md_fail(MDHIP_EVALUE, "unknown option %s", name ? name : "(null)");
+  *value_out = md_opt_table()[id];
+  return MDHIP_OK;
+}
 const char *mdhip_target(void) { return "host"; }
 const char *mdhip_last_error(void) { return md_err_slot().c_str(); }
 
@@ -574,9 +588,14 @@ int mdhip_vm_eval_reduce_cols(const mdhip_vm_program *pr, int op, const mdhip_ar
 }
 
 // data-parallel entry points: the double has no collective; world size 1 only.
-int mdhip_comm_probe(void) { return MDHIP_OK; }
-int mdhip_comm_get_unique_id(uint8_t uid[MDHIP_UID_BYTES]) { memset(uid, 0, MDHIP_UID_BYTES); return MDHIP_OK; }
 static int g_nranks = 0;
+int mdhip_comm_probe(void) { return MDHIP_OK; }
+int mdhip_comm_count(int *n) {
+  if (g_nranks != 1) return md_fail(MDHIP_ERUNTIME, "communicator not initialised");
+  *n = g_nranks;
+  return MDHIP_OK;
+}
+int mdhip_comm_get_unique_id(uint8_t uid[MDHIP_UID_BYTES]) { memset(uid, 0, MDHIP_UID_BYTES); return MDHIP_OK; }
 int mdhip_comm_init(int nranks, int, const uint8_t *) {
   if (nranks != 1) return md_fail(MDHIP_ERUNTIME, "host test double has no collective backend (nranks=%d)", nranks);
   g_nranks = 1;

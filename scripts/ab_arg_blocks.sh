@@ -1,3 +1,4 @@
+export MDHIP_EXPERIMENTS=1   # the library reads its experiment variables only behind this gate (csrc/md_options.h)
 cd /tmp; export TMPDIR=/tmp
 for b in 128 256 512; do
   MDHIP_ARG_BLOCKS=$b MISC_ONLY=0,10 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_arg_$b -- python3 $GRAFT_REPO_ROOT/scripts/misc_kernels.py > /dev/null 2>&1

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MDHIP_EXPERIMENTS=1   # the library reads its experiment variables only behind this gate (csrc/md_options.h)
 # A/B of the generated "evaluate + column-sum in one pass" kernel's geometry (MDHIP_SWEEP_NB bands per strip, MDHIP_SWEEP_RU rows
 # per trip; 0 = the library's choice) on cfg4 --lazy: the pass's own time from kernel-attached timestamps.
 for nb in 0 8 16 24 32 48 64; do for ru in 0 4 8; do

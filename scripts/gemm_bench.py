@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B the fp32 MFMA GEMM tile configs in ONE process (guide §5.4 rule 24):
 interleaved rounds over configs x layouts x shapes, HIP-event timing, random data.
-MDHIP_GEMM_CFG is read by libmdhip at every launch (experiments only)."""
+Tiles / staging / buffers are forced through the option table (mdhip_debug_set_option, csrc/md_options.h)."""
 import ctypes as C
 import os
 import sys
@@ -14,11 +14,11 @@ from minidiff_amd import _capi, ndarray as nd  # noqa: E402
 CFGS = {-1: "auto (tile picker)", 0: "128x128x16", 1: "64x64x16", 2: "128x64x16", 3: "256x128x16", 4: "256x256x32 (TN)", 5: "128x128x32 (TN)", 6: "128x64x32 (TN)", 7: "128x128 8 waves"}
 if os.environ.get("GEMM_CFGS"):
     CFGS = {int(k): CFGS[int(k)] for k in os.environ["GEMM_CFGS"].split(",")}
-if os.environ.get("GEMM_NBUF_AB"):   # every config twice: two / three LDS buffers in the k-contiguous direct-to-LDS kernel (MDHIP_GEMM_NBUF, read per launch)
+if os.environ.get("GEMM_NBUF_AB"):   # every config twice: two / three LDS buffers in the k-contiguous direct-to-LDS kernel (option gemm_nbuf)
     CFGS = {(99 if k == -1 else k) + 1000 * g: v + (" %dbuf" % (g + 2)) for k, v in CFGS.items() for g in (0, 1)}
-if os.environ.get("GEMM_PEEL_AB"):   # every config twice: single ragged launch / peeled (MDHIP_GEMM_PEEL, read per launch)
+if os.environ.get("GEMM_PEEL_AB"):   # every config twice: single ragged launch / peeled (option gemm_peel)
     CFGS = {(99 if k == -1 else k) + 10000 * g: v + (" peel" if g else " one launch") for k, v in CFGS.items() for g in (0, 1)}
-if os.environ.get("GEMM_GLDS_AB"):   # every config twice: register staging / direct-to-LDS staging (MDHIP_GEMM_GLDS is read per launch)
+if os.environ.get("GEMM_GLDS_AB"):   # every config twice: register staging / direct-to-LDS staging (option gemm_glds)
     CFGS = {(99 if k == -1 else k) + 100 * g: v + (" +glds" if g else "") for k, v in CFGS.items() for g in (0, 1)}   # (99 = auto)
 
 
@@ -27,6 +27,7 @@ REPS = int(os.environ.get("GEMM_REPS", "5"))   # launches per timing (small shap
 
 def main():
     lib = _capi.load()
+    opt = lambda name, v: lib.debug_set_option(name.encode(), int(v))   # noqa: E731
     shapes = [(4096, 4096, 4096), (2048, 2048, 2048), (8192, 4096, 4096), (1024, 4096, 4096), (4096, 1024, 4096)]
     if len(sys.argv) > 1:
         shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
@@ -47,15 +48,15 @@ def main():
         for rnd in range(rounds):
             for cfg in CFGS:
                 if os.environ.get("GEMM_NBUF_AB"):
-                    os.environ["MDHIP_GEMM_NBUF"] = str(2 + cfg // 1000)
+                    opt("gemm_nbuf", 2 + cfg // 1000)
                 if os.environ.get("GEMM_PEEL_AB"):
-                    os.environ["MDHIP_GEMM_PEEL"] = str(cfg // 10000)
+                    opt("gemm_peel", cfg // 10000)
                 if cfg % 100 == 99 or cfg == -1:
-                    os.environ.pop("MDHIP_GEMM_CFG", None)      # the library's own choice
+                    opt("gemm_cfg", -1)      # the library's own choice
                 else:
-                    os.environ["MDHIP_GEMM_CFG"] = str(cfg % 100)
+                    opt("gemm_cfg", cfg % 100)
                 if os.environ.get("GEMM_GLDS_AB"):
-                    os.environ["MDHIP_GEMM_GLDS"] = str(cfg // 100)
+                    opt("gemm_glds", cfg // 100)
                 combos = (("NN", A, B), ("NT", A, Bt.T), ("TN", At.T, B)) + ((("TT", At.T, Bt.T),) if os.environ.get("GEMM_TT") else ())
                 for tag, a, b in combos:
                     nd.matmul(a, b)  # warm
@@ -75,9 +76,7 @@ def main():
         print(f"M={M} K={K} N={N}")
         for cfg, name in CFGS.items():
             print("   %-22s " % name + "  ".join("%s med %6.1f min %6.1f max %6.1f TF" % (t, sorted(res[(cfg, t)])[len(res[(cfg, t)]) // 2], min(res[(cfg, t)]), max(res[(cfg, t)])) for t in (("NN", "NT", "TN", "TT") if os.environ.get("GEMM_TT") else ("NN", "NT", "TN"))))
-    os.environ.pop("MDHIP_GEMM_CFG", None)
-    os.environ.pop("MDHIP_GEMM_GLDS", None)
-    os.environ.pop("MDHIP_GEMM_NBUF", None)
+    opt("gemm_cfg", -1); opt("gemm_glds", 1); opt("gemm_nbuf", 0); opt("gemm_peel", 1)
 
 
 if __name__ == "__main__":

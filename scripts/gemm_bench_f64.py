@@ -31,14 +31,14 @@ def main():
         combos = (("NN", A, B, dAi, dBi), ("NT", A, Bt.T, dAi, dBit.T), ("TN", At.T, B, dAit.T, dBi))
         res = {}
         for glds in ("1", "0"):
-            os.environ["MDHIP_GEMM_GLDS"] = glds
+            lib.debug_set_option(b"gemm_glds", int(glds))
             for tag, a, b, ai, bi in combos:
                 assert np.array_equal(nd.matmul(ai, bi).get()[:256], ref), (tag, glds)
         for _ in range(8):          # pre-roll: clocks and allocator
             nd.matmul(A, B)
         for rnd in range(6):        # the two builds interleaved, round by round: drift shows in both rows
             for glds in ("1", "0"):
-                os.environ["MDHIP_GEMM_GLDS"] = glds
+                lib.debug_set_option(b"gemm_glds", int(glds))
                 for tag, a, b, ai, bi in combos:
                     nd.matmul(a, b)
                     lib.event_record(e0)
@@ -50,7 +50,7 @@ def main():
         for glds in ("1", "0"):
             line = ["%s med %5.1f max %5.1f TF" % (t, sorted(res[(glds, t)])[3], max(res[(glds, t)])) for t in ("NN", "NT", "TN")]
             print("   %-44s %s" % ("GLDS=1 (TN: direct-to-LDS; NN / NT: same kernel)" if glds == "1" else "GLDS=0 (register-staged everywhere)", "  ".join(line)))
-    os.environ.pop("MDHIP_GEMM_GLDS", None)
+    lib.debug_set_option(b"gemm_glds", 1)
 
 
 if __name__ == "__main__":

@@ -3,6 +3,7 @@
 s_memtime / s_memrealtime around every block's main loop into a persistent buffer (no sync behind the launches) and print the
 last launch's figures at exit.   usage: gemm_clock.py N LAYOUT [launches]"""
 import os, sys
+os.environ["MDHIP_EXPERIMENTS"] = "1"   # the library reads experiment variables only behind this gate
 os.environ["MDHIP_GEMM_STAMP"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C

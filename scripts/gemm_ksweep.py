@@ -4,6 +4,7 @@ cost of a k-tile, the intercept what a launch pays besides its main loop (prolog
 usage: gemm_ksweep.py [M N] ; MDHIP_GEMM_CFG / MDHIP_GEMM_GLDS select the kernel."""
 import ctypes as C
 import os
+os.environ.setdefault("MDHIP_EXPERIMENTS", "1")   # MDHIP_GEMM_CFG / MDHIP_GEMM_GLDS select the kernel: read only behind this gate
 import sys
 
 import numpy as np

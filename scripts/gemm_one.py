@@ -2,6 +2,7 @@
 """A handful of launches of one GEMM shape and layout (for rocprofv3 --pmc passes): MDHIP_GEMM_CFG selects the tile.
 usage: gemm_one.py M K N [NN|NT|TN]"""
 import os, sys
+os.environ.setdefault("MDHIP_EXPERIMENTS", "1")   # MDHIP_GEMM_CFG / MDHIP_GEMM_GLDS select the kernel: read only behind this gate
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from minidiff_amd import _capi, ndarray as nd

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MDHIP_EXPERIMENTS=1   # the library reads its experiment variables only behind this gate (csrc/md_options.h)
 # SQ counters of one GEMM shape/layout: where do the waves wait?  usage: gemm_pmc.sh TAG M K N LAYOUT(NN|NT|TN) [CFG]
 tag=$1; shift
 out=gpurun_out/$tag; mkdir -p $out; rm -rf $out/pmc; export TMPDIR=/tmp   # (a fresh directory per run: the summary below globs it)

@@ -3,7 +3,8 @@
 tests/test_isa_guard.py asserts so that a toolchain bump cannot silently undo the three compiler-steering devices the
 94 % of fp32 MFMA peak depends on.
 
-    isa_check.py [OBJ]      OBJ: build/mdhip/gemm.o (default) or any object / shared library with the gfx950 bundle
+    isa_check.py [OBJ]      OBJ: minidiff_amd/libmdhip.so (default: the SHIPPED library) or build/mdhip/gemm.o — any object
+                            or shared library; every gfx950 offload bundle in it is searched for the kernels
 
 Per kernel: MFMA count, LDS-DMA count, DMAs of the MAIN LOOP by address form (`vN, s[base]` scalar-base form vs the
 64-bit `v[N:N+1], off` form), v_lshl_add_u64 in the main loop, ds_write count, scratch use, and whether a `s_waitcnt
@@ -19,37 +20,33 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def disassemble(obj):
-    """-> text of `llvm-objdump -d --mcpu=gfx950` of the gfx950 code object bundled in `obj`."""
+def disassemble(obj, wanted=()):
+    """-> `llvm-objdump -d --mcpu=gfx950` text of the kernels of `obj` whose mangled names contain one of `wanted` (all
+    kernels when empty). `obj` may hold SEVERAL gfx950 offload bundles (a shared library has one per translation unit):
+    every bundle is unpacked, its symbol table searched, and only the matching symbols are disassembled."""
     tmp = tempfile.mkdtemp(prefix="mdhip_isa_")
     try:
         local = os.path.join(tmp, "in.o")
         shutil.copy(obj, local)
         subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", local], cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        co = [f for f in os.listdir(tmp) if "gfx950" in f]
-        if not co:
+        bundles = sorted(f for f in os.listdir(tmp) if "gfx950" in f)
+        if not bundles:
             raise RuntimeError(f"no gfx950 bundle in {obj}")
-        return subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", os.path.join(tmp, co[0])], check=True, capture_output=True, text=True).stdout
+        text = []
+        for co in bundles:
+            path = os.path.join(tmp, co)
+            if not wanted:
+                text.append(subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", path], check=True, capture_output=True, text=True).stdout)
+                continue
+            syms = subprocess.run([f"{LLVM}/llvm-objdump", "-t", path], check=True, capture_output=True, text=True).stdout
+            names = sorted({ln.split()[-1] for ln in syms.splitlines() if " F " in ln and any(w in ln for w in wanted)})
+            names = [n for n in names if not n.endswith(".kd")]
+            if names:
+                text.append(subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", "--disassemble-symbols=" + ",".join(names), path],
+                                           check=True, capture_output=True, text=True).stdout)
+        return "\n".join(text)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-
-
-def kernels(text):
-    """-> {mangled name: [instruction lines]}"""
-    out, cur = {}, None
-    for ln in text.splitlines():
-        m = re.match(r"^[0-9a-f]+ <(\S+)>:$", ln)
-        if m:
-            cur = out.setdefault(m.group(1), [])
-        elif cur is not None and ln.startswith("\t"):
-            cur.append(ln.strip().split("//")[0].strip())
-    return out
-
-
-def main_loop(ins):
-    """The innermost loop with the most MFMAs: instructions between a backward branch's target and the branch. The
-    objdump text has no labels, so the loop is found by address arithmetic on the branch offsets in the raw lines."""
-    raise NotImplementedError
 
 
 def analyse(name, raw_lines):
@@ -119,8 +116,8 @@ HEADLINE = {
 
 
 def report(obj=None):
-    obj = obj or os.path.join(ROOT, "build", "mdhip", "gemm.o")
-    ks = raw_kernels(disassemble(obj))
+    obj = obj or os.path.join(ROOT, "minidiff_amd", "libmdhip.so")
+    ks = raw_kernels(disassemble(obj, tuple(HEADLINE.values())))
     res = {}
     for label, frag in HEADLINE.items():
         names = [n for n in ks if frag in n]

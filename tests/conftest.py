@@ -66,6 +66,26 @@ def lib():
     return bound_library()[0]
 
 
+@pytest.fixture
+def mdopt(lib):
+    """Set entries of the library's option table (csrc/md_options.h) through the C-ABI test hook mdhip_debug_set_option —
+    tile forcing, staging scheme, legacy paths — and put the previous values back when the test ends. The environment is
+    NOT the way in: without MDHIP_EXPERIMENTS=1 the library ignores its experiment variables."""
+    import ctypes as C
+    saved = {}
+
+    def set_option(name, value):
+        if name not in saved:
+            old = C.c_int64()
+            lib.debug_get_option(name.encode(), C.byref(old))
+            saved[name] = old.value
+        lib.debug_set_option(name.encode(), int(value))
+
+    yield set_option
+    for name, old in saved.items():
+        lib.debug_set_option(name.encode(), old)
+
+
 @pytest.fixture(scope="session")
 def on_gpu():
     return bound_library()[1]

@@ -202,14 +202,14 @@ def test_weight_gradient_in_row_panels_is_bit_identical(engines, on_gpu):
 
 @pytest.mark.parametrize("glds", ["1", "0"])
 @pytest.mark.parametrize("tile", range(8))
-def test_every_gemm_tile_config_exact_on_integers(lib, on_gpu, tile, glds, monkeypatch):
-    """Every tile of the f32 MFMA kernel (gemm.hip's CFG_* list, forced through MDHIP_GEMM_CFG, which the library reads
-    at every launch), in the three layouts of definitions.py:487-492, whole and ragged shapes, plain and bias+relu
+def test_every_gemm_tile_config_exact_on_integers(lib, on_gpu, tile, glds, mdopt):
+    """Every tile of the f32 MFMA kernel (gemm.hip's CFG_* list, forced through the option gemm_cfg: mdhip_debug_set_option,
+    effective from the next launch), in the three layouts of definitions.py:487-492, whole and ragged shapes, plain and bias+relu
     epilogue kernels: small-integer operands make the f32 fma chain exact, so the results must EQUAL NumPy's."""
     assert on_gpu
     from minidiff_amd import ndarray as nd
-    monkeypatch.setenv("MDHIP_GEMM_CFG", str(tile))
-    monkeypatch.setenv("MDHIP_GEMM_GLDS", glds)     # direct-to-LDS kernels (whole aligned tiles) / register-staged kernels
+    mdopt("gemm_cfg", tile)
+    mdopt("gemm_glds", glds)     # direct-to-LDS kernels (whole aligned tiles) / register-staged kernels
     rng = np.random.default_rng(100 + tile)
     prev = nd.set_lazy(False)
     try:
@@ -273,11 +273,11 @@ def test_direct_to_lds_gemm_random_aligned_shapes(lib, on_gpu):
         nd.set_lazy(prev)
 
 
-def test_tt_products_run_as_the_swapped_nn_product(lib, on_gpu, monkeypatch):
+def test_tt_products_run_as_the_swapped_nn_product(lib, on_gpu, mdopt):
     """x.T @ y.T of two row-major arrays ("TT") has no kernel of its own: C^T = y x is the NN product of the two storages, run on
     the direct-to-LDS NN kernels with C addressed through swapped strides and stored as 16-B vectors along rows (gemm.hip,
     HipExec::gemm). Integer-valued operands: every product must EQUAL NumPy's and the register-staged TT kernel's
-    (MDHIP_GEMM_TT_SWAP=0); whole tiles of every size class, three-buffer grids, batches, ragged sizes."""
+    (option gemm_tt_swap = 0); whole tiles of every size class, three-buffer grids, batches, ragged sizes."""
     assert on_gpu
     from minidiff_amd import ndarray as nd
     rng = np.random.default_rng(77)
@@ -291,24 +291,23 @@ def test_tt_products_run_as_the_swapped_nn_product(lib, on_gpu, monkeypatch):
             xb = rng.integers(-3, 4, lead + (N, K)).astype(np.float32)      # B = xb^T
             da, db = nd.asarray(xa), nd.asarray(xb)
             ref = np.matmul(np.swapaxes(xa, -1, -2).astype(np.float64), np.swapaxes(xb, -1, -2).astype(np.float64))
-            monkeypatch.setenv("MDHIP_GEMM_TT_SWAP", "1")
+            mdopt("gemm_tt_swap", 1)
             got = nd.matmul(nd.swapaxes(da, -1, -2), nd.swapaxes(db, -1, -2))
             assert got.shape == ref.shape and got.is_c_contiguous
             assert np.array_equal(got.get(), ref), (M, K, N, batch)
-            monkeypatch.setenv("MDHIP_GEMM_TT_SWAP", "0")
+            mdopt("gemm_tt_swap", 0)
             old = nd.matmul(nd.swapaxes(da, -1, -2), nd.swapaxes(db, -1, -2))
             assert np.array_equal(old.get(), ref), (M, K, N, batch)
     finally:
         nd.set_lazy(prev)
 
 
-def test_misaligned_operands_of_large_products_are_repacked(lib, on_gpu):
+def test_misaligned_operands_of_large_products_are_repacked(lib, on_gpu, mdopt):
     """Odd leading dimensions (x.T of a matrix with an odd column count) and views that start off a 16-byte boundary: large
     products copy such an operand once into an aligned, row-padded buffer and take the direct-to-LDS kernels (gemm.hip,
     HipExec::gemm); the padding must never reach C. Integer-valued operands: the products must EQUAL NumPy's, in every layout,
     with the repack on and off."""
     assert on_gpu
-    import os
     from minidiff_amd import ndarray as nd
     rng = np.random.default_rng(4097)
     prev = nd.set_lazy(False)
@@ -324,10 +323,10 @@ def test_misaligned_operands_of_large_products_are_repacked(lib, on_gpu):
                     (ha, da), (hb, db) = make(M, K, lay[0] == "T"), make(K, N, lay[1] == "T")
                     ref = np.matmul(ha.astype(np.float64), hb.astype(np.float64))
                     for flag in ("1", "0"):
-                        os.environ["MDHIP_GEMM_REPACK"] = flag      # (read once per process: '0' only matters if it was set before the first product)
+                        mdopt("gemm_repack", flag)      # (effective from the next launch: the "0" leg really runs the edge kernels)
                         got = nd.matmul(da, db).get()
                         assert np.array_equal(got, ref), (M, K, N, lay, off, flag)
-        os.environ.pop("MDHIP_GEMM_REPACK", None)
+        mdopt("gemm_repack", 1)
         # the shape DESIGN §9.1 quotes, TN with an odd M: result against float64
         M, K, N = 4097, 4096, 4100
         a = rng.standard_normal((K, M), dtype=np.float32)
@@ -341,11 +340,11 @@ def test_misaligned_operands_of_large_products_are_repacked(lib, on_gpu):
         nd.set_lazy(prev)
 
 
-def test_peeled_ragged_products(lib, on_gpu, monkeypatch):
+def test_peeled_ragged_products(lib, on_gpu, mdopt):
     """A product a few rows / columns past a multiple of 256 runs as an aligned main block on the whole-tile kernels plus a bottom
-    and a right strip (gemm.hip, launch_mfma_peeled). Forced here (MDHIP_GEMM_PEEL=2) on every layout, with thin and fat strips,
+    and a right strip (gemm.hip, launch_mfma_peeled). Forced here (option gemm_peel = 2) on every layout, with thin and fat strips,
     batches, odd leading dimensions (repacked operands) and K that the peel refuses: integer-valued operands, the products must
-    EQUAL NumPy's and the single-launch result (MDHIP_GEMM_PEEL=0)."""
+    EQUAL NumPy's and the single-launch result (gemm_peel = 0)."""
     assert on_gpu
     from minidiff_amd import ndarray as nd
     rng = np.random.default_rng(256)
@@ -363,10 +362,10 @@ def test_peeled_ragged_products(lib, on_gpu, monkeypatch):
                 (ha, da), (hb, db) = make(M, K, lay[0] == "T"), make(K, N, lay[1] == "T")
                 ref = np.matmul(ha.astype(np.float64), hb.astype(np.float64))
                 for mode in ("2", "1", "0"):
-                    monkeypatch.setenv("MDHIP_GEMM_PEEL", mode)
+                    mdopt("gemm_peel", mode)
                     assert np.array_equal(nd.matmul(da, db).get(), ref), (M, K, N, batch, lay, mode)
         # the model's own choice at the shape the peel exists for (TN, odd M: repacked A, one bottom row, four right columns)
-        monkeypatch.delenv("MDHIP_GEMM_PEEL")
+        mdopt("gemm_peel", 1)
         M, K, N = 4097, 1024, 4100
         a = rng.integers(-2, 3, (K, M)).astype(np.float32)
         b = rng.integers(-2, 3, (K, N)).astype(np.float32)

@@ -221,3 +221,66 @@ def test_sweep_cache_replays_and_recaptures_changed_graph(engines):
                 assert new, "after the re-capture every run must follow the new structure"
             seen_new = seen_new or new
         assert seen_new and cache.stats["invalidated"] == 1 and cache.stats["captured"] == 2
+
+
+def test_sweep_signature_never_copies_arrays_to_the_host(engines, monkeypatch):
+    """`_signature` used to repr() every non-Tensor op input — a getitem key holding Tensors / device arrays reached
+    DeviceArray.__repr__ -> .get(): one D2H copy and a stream sync per such op in every backward() under reuse_graph (and, inside
+    a stream capture, an uncapturable sweep). Array-likes are now identified by (type, shape, dtype, first-sighting index)."""
+    from minidiff_amd.graph import SweepCache
+    hip, _ = engines
+    x = hip.Tensor(np.arange(24.0).reshape(6, 4) / 8, allow_grad=True)
+    idx = hip.Tensor(np.array([4, 0, 4, 2]))
+    idx2 = hip.Tensor(np.array([1, 1, 3]))
+    raw = nd.asarray(np.array([5, 5, 0]))            # a raw DeviceArray inside the key
+    gets = {"n": 0}
+    plain_get = nd.DeviceArray.get
+
+    def counting_get(self, *a, **kw):
+        gets["n"] += 1
+        return plain_get(self, *a, **kw)
+
+    cache = SweepCache(hip)
+    keys = {}
+    monkeypatch.setattr(nd.DeviceArray, "get", counting_get)
+    for name, key in (("t", (idx, slice(None))), ("t_again", (idx, slice(None))), ("t_other_shape", (idx2, slice(None))),
+                      ("raw", (raw, slice(1, 3))), ("raw_slice2", (raw, slice(0, 3)))):
+        with hip.reuse_graph():
+            x.grad = None
+            hip.sum(x[key] * 2.0).backward()
+            keys[name] = cache._key()
+    monkeypatch.undo()
+    assert gets["n"] == 0, "the sweep signature must not read device arrays back"
+    assert keys["t"] == keys["t_again"]
+    assert len({keys["t"], keys["t_other_shape"], keys["raw"], keys["raw_slice2"]}) == 4
+    # small HOST constants are still told apart by value (a replay bakes their upload in), without a repr of the device side
+    with hip.reuse_graph():
+        hip.sum(x * np.array([1.0, 2.0, 3.0, 4.0])).backward(); k1 = cache._key()
+        hip.sum(x * np.array([1.0, 2.0, 3.0, 5.0])).backward(); k2 = cache._key()
+    assert k1 != k2
+    cache.close()
+
+
+@pytest.mark.gpu
+def test_tensor_indexed_getitem_sweep_is_captured(engines):
+    """... and such a sweep (gather by a resident index tensor, scatter-add in the backward) is captured and replayed by SweepCache:
+    the signature no longer synchronises inside the capture."""
+    from minidiff_amd.graph import SweepCache
+    hip, _ = engines
+    rng = np.random.default_rng(11)
+    xh = rng.standard_normal((64, 32)).astype(np.float32)
+    ih = rng.integers(0, 64, 200)
+    x, idx = hip.Tensor(xh, allow_grad=True), hip.Tensor(ih)
+
+    def step():
+        x.grad = None
+        hip.sum(x[(idx, slice(None))] * 3.0).backward()
+        return {"gx": x.grad}
+
+    exp = np.zeros_like(xh)
+    np.add.at(exp, ih, np.float32(3.0))
+    with SweepCache(hip, validate_every=0) as cache:
+        for _ in range(5):
+            out = cache.run(step)
+            np.testing.assert_array_equal(out["gx"].as_numpy(), exp)
+        assert cache.stats["captured"] == 1 and cache.stats["replayed"] >= 2 and cache.stats["uncapturable"] == 0, cache.stats

@@ -386,12 +386,11 @@ def test_f64_matmul_mfma_gpu(lib, on_gpu):
 
 
 @gpu
-def test_f64_tn_direct_to_lds_gpu(lib, on_gpu):
+def test_f64_tn_direct_to_lds_gpu(lib, on_gpu, mdopt):
     """k_gemm_f64_tn_glds (TN products of whole aligned 128 x 128 x 16 tiles on grids of >= 256 tiles): integer-valued operands,
     so every element must EQUAL NumPy's — whole arrays, batched, a sub-view with a larger row stride — with the direct-to-LDS
-    kernel on and off (MDHIP_GEMM_GLDS is read at every launch), and the random-data result within 1e-14 of NumPy's."""
+    kernel on and off (option gemm_glds, mdhip_debug_set_option), and the random-data result within 1e-14 of NumPy's."""
     assert on_gpu
-    import os
     rng = np.random.default_rng(19)
     try:
         for (M, K, N, batch) in ((2048, 96, 2048, 0), (2048, 512, 2048, 0), (1024, 64, 1024, 4), (4096, 32, 2048, 0)):
@@ -402,13 +401,13 @@ def test_f64_tn_direct_to_lds_gpu(lib, on_gpu):
             ha = big_a[..., :, 2:M + 2]
             ref = np.matmul(np.swapaxes(ha, -1, -2), big_b)
             for flag in ("1", "0"):
-                os.environ["MDHIP_GEMM_GLDS"] = flag
+                mdopt("gemm_glds", flag)
                 got = nd.matmul(nd.swapaxes(da, -1, -2), db).get()
                 assert np.array_equal(got, ref), (M, K, N, batch, flag)
-        os.environ["MDHIP_GEMM_GLDS"] = "1"
+        mdopt("gemm_glds", 1)
         a, b = rng.standard_normal((512, 2048)), rng.standard_normal((512, 2048))
         got = nd.matmul(nd.asarray(a).T, nd.asarray(b)).get()
         ref = a.T @ b
         assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-14
     finally:
-        os.environ.pop("MDHIP_GEMM_GLDS", None)
+        mdopt("gemm_glds", 1)
