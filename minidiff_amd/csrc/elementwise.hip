@@ -574,9 +574,19 @@ __global__ void __launch_bounds__(MD_BLOCK) k_convert(MdIter it, const void *x, 
 
 }  // namespace
 
+// narrow.hip: the same entry points when a storage-only dtype (int8/16, uint8/16/32/64, float16) takes part
+int md_narrow_unary(int op, const mdhip_array *x, const mdhip_array *out);
+int md_narrow_binary(int op, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out, int cdt);
+int md_narrow_where(const mdhip_array *c, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out);
+static inline bool md_narrow_code(int dt) { return dt >= MDHIP_NUM_DTYPES && dt < MDHIP_NUM_ALL_DTYPES; }
+static inline bool md_narrow_arr(const mdhip_array *a) { return a && !a->is_scalar && md_narrow_code(a->dtype); }
+
 extern "C" {
 
-int mdhip_unary(int op, const mdhip_array *x, const mdhip_array *out) { return md_unary_dispatch<HipExec>(op, x, out); }
+int mdhip_unary(int op, const mdhip_array *x, const mdhip_array *out) {
+  if (op != MDHIP_U_COPY && x && out && (md_narrow_arr(x) || md_narrow_arr(out))) return md_narrow_unary(op, x, out);
+  return md_unary_dispatch<HipExec>(op, x, out);
+}
 
 int mdhip_convert(const mdhip_array *x, const mdhip_array *out) {
   MD_TRY(md_check_any_array(x, "convert x"));
@@ -595,10 +605,12 @@ int mdhip_convert(const mdhip_array *x, const mdhip_array *out) {
 }
 
 int mdhip_binary(int op, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out, int cdt) {
+  if (a && b && out && (md_narrow_arr(a) || md_narrow_arr(b) || md_narrow_arr(out) || md_narrow_code(cdt))) return md_narrow_binary(op, a, b, out, cdt);
   return md_binary_dispatch<HipExec>(op, a, b, out, cdt);
 }
 
 int mdhip_where(const mdhip_array *c, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out) {
+  if (c && a && b && out && (md_narrow_arr(c) || md_narrow_arr(a) || md_narrow_arr(b) || md_narrow_arr(out))) return md_narrow_where(c, a, b, out);
   return md_where_dispatch<HipExec>(c, a, b, out);
 }
 

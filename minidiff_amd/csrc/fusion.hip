@@ -369,11 +369,12 @@ template <class T> static int eval_typed(const mdhip_vm_program *pr, const mdhip
       jit::spec_modes(&S, D, rows);
       S.out_bool = to_bool;
       S.nt = bytes > ((int64_t)320 << 20);
+      jit::eval_shape(&S);
       if (hipFunction_t fn = jit::get(S)) {
         jit::JArgs A;
         jit::fill_args(&A, pr, D);
         A.outs[0] = out->data;
-        const int grid = jit::stream_grid(&A, rows, inner);
+        const int grid = jit::stream_grid(&A, rows, inner, jit::eval_blocks(S));
         return jit::launch(fn, A, dim3((unsigned)grid));
       }
     }
@@ -461,6 +462,7 @@ static int eval_multi(const mdhip_vm_program *progs, const mdhip_array *outs, in
     if (D.leaf[l].is) bytes += it.total * (int64_t)md_dtype_size(merged.leaves[l].dtype);
   jit::spec_modes(&M, D, rows);
   M.nt = bytes > ((int64_t)320 << 20);
+  jit::eval_shape(&M);
   hipFunction_t fn = jit::get(M);
   if (!fn) return MDHIP_OK;
   jit::JArgs A;
@@ -468,7 +470,7 @@ static int eval_multi(const mdhip_vm_program *progs, const mdhip_array *outs, in
   for (int l = 0; l < merged.n_leaves; ++l) { A.leaf[l].p = D.leaf[l].p; A.leaf[l].os = D.leaf[l].os; A.leaf[l].is = D.leaf[l].is; }
   for (int i = 0; i < M.n_imm; ++i) A.imm[i] = merged.imm[i];
   for (int k = 0; k < n; ++k) A.outs[k] = outs[k].data;
-  const int grid = jit::stream_grid(&A, rows, inner);
+  const int grid = jit::stream_grid(&A, rows, inner, jit::eval_blocks(M));
   *done = true;
   return jit::launch(fn, A, dim3((unsigned)grid));
 }

@@ -67,17 +67,22 @@ template <> struct md_dtype_of<b8> { static constexpr int value = MDHIP_BOOL; };
 template <> struct md_dtype_of<uint8_t> { static constexpr int value = MDHIP_BOOL; };
 template <> struct md_dtype_of<int32_t> { static constexpr int value = MDHIP_I32; };
 template <> struct md_dtype_of<int64_t> { static constexpr int value = MDHIP_I64; };
+template <> struct md_dtype_of<uint64_t> { static constexpr int value = MDHIP_U64; };
 template <> struct md_dtype_of<float> { static constexpr int value = MDHIP_F32; };
 template <> struct md_dtype_of<double> { static constexpr int value = MDHIP_F64; };
 
 // ---- typed element access with a runtime source dtype ------------------------
 // Tc == uint8_t means "truth value": any source dtype loads as (x != 0).
+// (the seven storage-only dtypes of include/mdhip.h load like the five compute dtypes: one conversion to the compute type —
+// what NumPy's cast of an operand to the loop dtype does; the switch is wave-uniform)
 template <class Tc> MD_HD Tc md_load(const void *p, int dtype, int64_t off) {
   if constexpr (md_same<Tc, uint8_t>::value) {
     switch (dtype) {
-      case MDHIP_BOOL: return (uint8_t)(((const uint8_t *)p)[off] != 0);
-      case MDHIP_I32: return (uint8_t)(((const int32_t *)p)[off] != 0);
-      case MDHIP_I64: return (uint8_t)(((const int64_t *)p)[off] != 0);
+      case MDHIP_BOOL: case MDHIP_I8: case MDHIP_U8: return (uint8_t)(((const uint8_t *)p)[off] != 0);
+      case MDHIP_I16: case MDHIP_U16: return (uint8_t)(((const uint16_t *)p)[off] != 0);
+      case MDHIP_F16: return (uint8_t)((((const uint16_t *)p)[off] & 0x7FFFu) != 0);   // (-0.0 is false, NaN is true)
+      case MDHIP_I32: case MDHIP_U32: return (uint8_t)(((const int32_t *)p)[off] != 0);
+      case MDHIP_I64: case MDHIP_U64: return (uint8_t)(((const int64_t *)p)[off] != 0);
       case MDHIP_F32: return (uint8_t)(((const float *)p)[off] != 0.0f);
       default: return (uint8_t)(((const double *)p)[off] != 0.0);
     }
@@ -87,7 +92,41 @@ template <class Tc> MD_HD Tc md_load(const void *p, int dtype, int64_t off) {
       case MDHIP_I32: return md_cast<Tc>(((const int32_t *)p)[off]);
       case MDHIP_I64: return md_cast<Tc>(((const int64_t *)p)[off]);
       case MDHIP_F32: return md_cast<Tc>(((const float *)p)[off]);
+      case MDHIP_I8: return md_cast<Tc>(((const int8_t *)p)[off]);
+      case MDHIP_I16: return md_cast<Tc>(((const int16_t *)p)[off]);
+      case MDHIP_U8: return md_cast<Tc>(((const uint8_t *)p)[off]);
+      case MDHIP_U16: return md_cast<Tc>(((const uint16_t *)p)[off]);
+      case MDHIP_U32: return md_cast<Tc>(((const uint32_t *)p)[off]);
+      case MDHIP_U64: return md_cast<Tc>(((const uint64_t *)p)[off]);
+      case MDHIP_F16: return md_cast<Tc>(((const f16 *)p)[off]);
       default: return md_cast<Tc>(((const double *)p)[off]);
+    }
+  }
+}
+// store a result of the compute type (or a truth value b8) into an array of ANY of the twelve dtypes: integer destinations
+// truncate (two's-complement wrap-around — the narrow result of an operation carried out in a wider integer), floats round once
+template <class R> MD_HD void md_store_as(void *p, int dtype, int64_t off, R v) {
+  if constexpr (md_same<R, b8>::value) {
+    switch (dtype) {
+      case MDHIP_BOOL: case MDHIP_I8: case MDHIP_U8: ((uint8_t *)p)[off] = v.v; return;
+      case MDHIP_I16: case MDHIP_U16: ((uint16_t *)p)[off] = v.v; return;
+      case MDHIP_I32: case MDHIP_U32: ((uint32_t *)p)[off] = v.v; return;
+      case MDHIP_I64: case MDHIP_U64: ((uint64_t *)p)[off] = v.v; return;
+      case MDHIP_F16: ((f16 *)p)[off] = md_cast<f16>((float)v.v); return;
+      case MDHIP_F32: ((float *)p)[off] = (float)v.v; return;
+      default: ((double *)p)[off] = (double)v.v; return;
+    }
+  } else {
+    switch (dtype) {
+      case MDHIP_BOOL: ((uint8_t *)p)[off] = (uint8_t)(v != (R)0); return;
+      case MDHIP_I8: case MDHIP_U8: ((uint8_t *)p)[off] = (uint8_t)md_cast<int64_t>(v); return;
+      case MDHIP_I16: case MDHIP_U16: ((uint16_t *)p)[off] = (uint16_t)md_cast<int64_t>(v); return;
+      case MDHIP_I32: case MDHIP_U32: ((uint32_t *)p)[off] = (uint32_t)md_cast<int64_t>(v); return;
+      case MDHIP_I64: ((int64_t *)p)[off] = md_cast<int64_t>(v); return;
+      case MDHIP_U64: ((uint64_t *)p)[off] = md_cast<uint64_t>(v); return;
+      case MDHIP_F16: ((f16 *)p)[off] = md_cast<f16>(v); return;
+      case MDHIP_F32: ((float *)p)[off] = (float)v; return;
+      default: ((double *)p)[off] = (double)v; return;
     }
   }
 }
@@ -104,40 +143,7 @@ template <class Tc> static inline Tc md_scalar_as(const mdhip_array *s) {
 }
 
 // ---- storage-only dtypes: conversion through a carrier (mdhip_convert) ---------------
-// binary16 by bit manipulation (no _Float16 in the host toolchain): exact widening, round-to-nearest-even narrowing
-// straight from double (a float widens to double exactly, so one routine serves both without double rounding)
-MD_HD double md_half_to_double(uint16_t h) {
-  const uint32_t sign = (h >> 15) & 1u, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
-  double v;
-  if (e == 0) v = (double)m * 5.9604644775390625e-08;                 // subnormal: m * 2^-24
-  else if (e == 31) { v = m ? __builtin_nan("") : __builtin_inf(); }
-  else {
-    uint64_t bits = ((uint64_t)(e + 1008u) << 52) | ((uint64_t)m << 42);   // exponent bias 1023 - 15
-    __builtin_memcpy(&v, &bits, 8);
-  }
-  return sign ? -v : v;
-}
-MD_HD uint16_t md_double_to_half(double d) {
-  uint64_t b;
-  __builtin_memcpy(&b, &d, 8);
-  const uint16_t sign = (uint16_t)((b >> 48) & 0x8000u);
-  const int64_t e = (int64_t)((b >> 52) & 0x7FF) - 1023;
-  uint64_t m = b & 0xFFFFFFFFFFFFFull;
-  if (e == 1024) return (uint16_t)(sign | 0x7C00u | (m ? 0x200u : 0u));           // inf / nan
-  if (e > 15) return (uint16_t)(sign | 0x7C00u);                                    // overflow -> inf
-  if (e >= -14) {                                                                   // normal half
-    uint64_t q = m >> 42, rem = m & ((1ull << 42) - 1), half = 1ull << 41;
-    uint32_t r = (uint32_t)(((uint64_t)(e + 15) << 10) | q);
-    if (rem > half || (rem == half && (r & 1u))) ++r;                               // carries into the exponent correctly, up to inf
-    return (uint16_t)(sign | r);
-  }
-  if (e < -25) return sign;                                                         // below half of the smallest subnormal
-  m |= 1ull << 52;                                                                  // subnormal half: value = m * 2^(e-52), unit 2^-24
-  const int shift = (int)(28 - e);                                                  // 52 - (e + 24)
-  uint64_t q = m >> shift, rem = m & ((1ull << shift) - 1), half = 1ull << (shift - 1);
-  if (rem > half || (rem == half && (q & 1u))) ++q;
-  return (uint16_t)(sign | (uint16_t)q);
-}
+// (binary16 <-> double by bit manipulation: md_half_to_double / md_double_to_half, md_ops.h)
 // carrier of a dtype: 0 = int64 (signed ints, bool), 1 = uint64 (unsigned ints), 2 = double (floats)
 static inline int md_dtype_carrier(int dt) {
   switch (dt) {

@@ -205,9 +205,19 @@ template <class X> int md_where_dispatch(const mdhip_array *cond, const mdhip_ar
 }
 
 // ================================ reduce =======================================
-template <class X> int md_reduce_dispatch(int op, const mdhip_array *x, const mdhip_array *out, uint32_t mask) {
-  MD_TRY(md_check_array(x, "reduce x"));
-  MD_TRY(md_check_array(out, "reduce out"));
+// x may be of ANY of the twelve dtypes: the reduction kernels load through md_load (one conversion to the accumulator type,
+// what NumPy's cast to the loop dtype does); `out` is one of the five compute dtypes — or uint64 for sums / products, which
+// accumulate in int64 with the same bits — except for MAX / MIN of uint64, which compare as unsigned. A caller that wants a
+// storage-only RESULT dtype (max of int8 -> int8, sum of float16 -> float16) reduces into the carrier type and converts the
+// (small) result: mdhip_reduce does that itself.
+template <class X> int md_reduce_dispatch(int op, const mdhip_array *x, const mdhip_array *out_in, uint32_t mask) {
+  MD_TRY(md_check_any_array(x, "reduce x"));
+  MD_TRY(md_check_any_array(out_in, "reduce out"));
+  mdhip_array out_v = *out_in;
+  if (out_v.dtype == MDHIP_U64 && (op == MDHIP_R_SUM || op == MDHIP_R_PROD)) out_v.dtype = MDHIP_I64;   // same bits modulo 2^64
+  const mdhip_array *out = &out_v;
+  const bool u64_cmp = (op == MDHIP_R_MAX || op == MDHIP_R_MIN) && x->dtype == MDHIP_U64 && out->dtype == MDHIP_U64;
+  if (!u64_cmp) MD_TRY(md_check_array(out, "reduce out"));
   if (x->is_scalar || out->is_scalar) return md_fail(MDHIP_EVALUE, "reduce: scalar operands not accepted");
   MdRedPlan pl;
   MD_TRY(md_build_redplan(&pl, x, out, mask));
@@ -232,6 +242,16 @@ template <class X> int md_reduce_dispatch(int op, const mdhip_array *x, const md
     case MDHIP_R_MAX:
     case MDHIP_R_MIN:
       if (pl.n_red == 0) return md_fail(MDHIP_EVALUE, "zero-size array to reduction operation %s which has no identity", op == MDHIP_R_MAX ? "maximum" : "minimum");
+      if (u64_cmp) return op == MDHIP_R_MAX ? X::template reduce<RMax, uint64_t, uint64_t>(pl, x, out) : X::template reduce<RMin, uint64_t, uint64_t>(pl, x, out);
+      // (a storage-only input compares in its carrier type: `out` then has the carrier's dtype)
+      if (xdt >= MDHIP_NUM_DTYPES) {
+        switch (odt) {
+          case MDHIP_I32: return op == MDHIP_R_MAX ? X::template reduce<RMax, int32_t, int32_t>(pl, x, out) : X::template reduce<RMin, int32_t, int32_t>(pl, x, out);
+          case MDHIP_I64: return op == MDHIP_R_MAX ? X::template reduce<RMax, int64_t, int64_t>(pl, x, out) : X::template reduce<RMin, int64_t, int64_t>(pl, x, out);
+          case MDHIP_F32: return op == MDHIP_R_MAX ? X::template reduce<RMax, float, float>(pl, x, out) : X::template reduce<RMin, float, float>(pl, x, out);
+        }
+        return md_fail(MDHIP_ETYPE, "max/min of %s: out must have the carrier dtype", md_dtype_name(xdt));
+      }
       if (odt != xdt) return md_fail(MDHIP_ETYPE, "max/min: out dtype must equal input dtype");
       MD_ALL_SWITCH(xdt, T, {
         using To = typename md_cond<md_same<T, uint8_t>::value, b8, T>::type;
@@ -247,6 +267,16 @@ template <class X> int md_reduce_dispatch(int op, const mdhip_array *x, const md
     case MDHIP_R_ARGMIN:
       if (pl.n_red == 0) return md_fail(MDHIP_EVALUE, "attempt to get %s of an empty sequence", op == MDHIP_R_ARGMAX ? "argmax" : "argmin");
       if (odt != MDHIP_I64) return md_fail(MDHIP_ETYPE, "argmax/argmin: out must be int64");
+      switch (xdt) {   // storage-only inputs compare in their carrier type
+        case MDHIP_I8: case MDHIP_I16: case MDHIP_U8: case MDHIP_U16:
+          return op == MDHIP_R_ARGMAX ? X::template argreduce<true, int32_t>(pl, x, out) : X::template argreduce<false, int32_t>(pl, x, out);
+        case MDHIP_U32:
+          return op == MDHIP_R_ARGMAX ? X::template argreduce<true, int64_t>(pl, x, out) : X::template argreduce<false, int64_t>(pl, x, out);
+        case MDHIP_U64:
+          return op == MDHIP_R_ARGMAX ? X::template argreduce<true, uint64_t>(pl, x, out) : X::template argreduce<false, uint64_t>(pl, x, out);
+        case MDHIP_F16:
+          return op == MDHIP_R_ARGMAX ? X::template argreduce<true, float>(pl, x, out) : X::template argreduce<false, float>(pl, x, out);
+      }
       MD_ALL_SWITCH(xdt, T, {
         return op == MDHIP_R_ARGMAX ? X::template argreduce<true, T>(pl, x, out)
                                     : X::template argreduce<false, T>(pl, x, out);

@@ -15,6 +15,8 @@
 #if defined(__HIPCC_RTC__)
 typedef signed char int8_t;
 typedef unsigned char uint8_t;
+typedef short int16_t;
+typedef unsigned short uint16_t;
 typedef int int32_t;
 typedef unsigned int uint32_t;
 typedef long long int64_t;
@@ -55,8 +57,90 @@ template <class T> struct md_is_float { static constexpr bool value = false; };
 template <> struct md_is_float<float> { static constexpr bool value = true; };
 template <> struct md_is_float<double> { static constexpr bool value = true; };
 
+template <class T> struct md_is_unsigned { static constexpr bool value = false; };
+template <> struct md_is_unsigned<uint8_t> { static constexpr bool value = true; };
+template <> struct md_is_unsigned<uint16_t> { static constexpr bool value = true; };
+template <> struct md_is_unsigned<uint32_t> { static constexpr bool value = true; };
+template <> struct md_is_unsigned<uint64_t> { static constexpr bool value = true; };
+
+// IEEE binary16 as a STORAGE type (numpy.float16): arithmetic on it runs in float32 and rounds once on the way back, as NumPy's
+// own half loops do. Host builds convert by bit manipulation (no _Float16 in the host toolchain), device builds in hardware.
+struct f16 {
+  uint16_t bits;
+};
+MD_HD double md_half_to_double(uint16_t h) {
+  const uint32_t sign = (h >> 15) & 1u, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+  double v;
+  if (e == 0) v = (double)m * 5.9604644775390625e-08;                 // subnormal: m * 2^-24
+  else if (e == 31) { v = m ? __builtin_nan("") : __builtin_inf(); }
+  else {
+    uint64_t bits = ((uint64_t)(e + 1008u) << 52) | ((uint64_t)m << 42);   // exponent bias 1023 - 15
+    __builtin_memcpy(&v, &bits, 8);
+  }
+  return sign ? -v : v;
+}
+// round-to-nearest-even straight from double (a float widens to double exactly, so one routine serves both without double rounding)
+MD_HD uint16_t md_double_to_half(double d) {
+  uint64_t b;
+  __builtin_memcpy(&b, &d, 8);
+  const uint16_t sign = (uint16_t)((b >> 48) & 0x8000u);
+  const int64_t e = (int64_t)((b >> 52) & 0x7FF) - 1023;
+  uint64_t m = b & 0xFFFFFFFFFFFFFull;
+  if (e == 1024) return (uint16_t)(sign | 0x7C00u | (m ? 0x200u : 0u));           // inf / nan
+  if (e > 15) return (uint16_t)(sign | 0x7C00u);                                    // overflow -> inf
+  if (e >= -14) {                                                                   // normal half
+    uint64_t q = m >> 42, rem = m & ((1ull << 42) - 1), half = 1ull << 41;
+    uint32_t r = (uint32_t)(((uint64_t)(e + 15) << 10) | q);
+    if (rem > half || (rem == half && (r & 1u))) ++r;                               // carries into the exponent correctly, up to inf
+    return (uint16_t)(sign | r);
+  }
+  if (e < -25) return sign;                                                         // below half of the smallest subnormal
+  m |= 1ull << 52;                                                                  // subnormal half: value = m * 2^(e-52), unit 2^-24
+  const int shift = (int)(28 - e);                                                  // 52 - (e + 24)
+  uint64_t q = m >> shift, rem = m & ((1ull << shift) - 1), half = 1ull << (shift - 1);
+  if (rem > half || (rem == half && (q & 1u))) ++q;
+  return (uint16_t)(sign | (uint16_t)q);
+}
+MD_HD float md_f16_to_float(f16 h) {
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)
+  _Float16 v;
+  __builtin_memcpy(&v, &h.bits, 2);
+  return (float)v;
+#else
+  return (float)md_half_to_double(h.bits);
+#endif
+}
+MD_HD f16 md_float_to_f16(float x) {
+  f16 h;
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)
+  const _Float16 v = (_Float16)x;   // round-to-nearest-even (v_cvt_f16_f32)
+  __builtin_memcpy(&h.bits, &v, 2);
+#else
+  h.bits = md_double_to_half((double)x);
+#endif
+  return h;
+}
+
 template <class To, class From> struct md_caster {
   static MD_HD To run(From x) { return (To)x; }
+};
+template <class To> struct md_caster<To, f16> {
+  static MD_HD To run(f16 x) { return (To)md_f16_to_float(x); }
+};
+template <class From> struct md_caster<f16, From> {
+  static MD_HD f16 run(From x) { return md_float_to_f16((float)x); }
+};
+template <> struct md_caster<f16, double> {
+  static MD_HD f16 run(double x) { f16 h; h.bits = md_double_to_half(x); return h; }
+};
+template <> struct md_caster<f16, f16> {
+  static MD_HD f16 run(f16 x) { return x; }
+};
+template <> struct md_caster<f16, b8> {
+  static MD_HD f16 run(b8 x) { return md_float_to_f16((float)x.v); }
+};
+template <> struct md_caster<b8, f16> {
+  static MD_HD b8 run(f16 x) { return b8{(uint8_t)((x.bits & 0x7FFFu) != 0)}; }
 };
 template <class From> struct md_caster<b8, From> {
   static MD_HD b8 run(From x) { return b8{(uint8_t)(x != (From)0)}; }
@@ -93,8 +177,6 @@ template <class To, class From> MD_HD To md_cast(From x) { return md_caster<To, 
 #define MD_MATH1(name, ffn, dfn)                   \
   MD_HD float md_##name(float x) { return ffn(x); } \
   MD_HD double md_##name(double x) { return dfn(x); }
-MD_MATH1(sin, sinf, sin)
-MD_MATH1(cos, cosf, cos)
 MD_MATH1(tan, tanf, tan)
 MD_MATH1(sinh, sinhf, sinh)
 MD_MATH1(cosh, coshf, cosh)
@@ -105,16 +187,55 @@ MD_MATH1(sqrt, sqrtf, sqrt)
 MD_MATH1(ceil, ceilf, ceil)
 MD_MATH1(floor, floorf, floor)
 MD_MATH1(fabs, fabsf, fabs)
-#undef MD_MATH1
-// sin and cos of one argument with ONE argument reduction (device: OCML sincos — the same reduction and
-// polynomials as sinf / cosf, so each result equals the separate call bit for bit; tests/test_lazy_fusion.py)
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)
-MD_HD void md_sincos(float x, float *s, float *c) { sincosf(x, s, c); }
+// float32 sin / cos on the device. OCML's sinf / cosf decide small / large argument PER ELEMENT with an exec-masked branch each
+// and carry the Payne-Hanek path inline: the streaming `sin` of 1e8 elements issued ~60 vector instructions per element and ran
+// VALU-bound at 68-70 % of the HBM roofline (rocprofv3, profiles/r3_cfg3_kernel_stats.csv; ISA: 753 vector instructions per 4
+// elements). Here: ONE branch-free path for |x| <= 105615 — three-constant Cody-Waite reduction by pi/2 with fused multiply-adds,
+// minimax polynomials on [-pi/4, pi/4], both polynomials evaluated and chosen by quadrant — 21 instructions for sin AND cos
+// together, maximum error 1.5 ulp (checked against float64 over 1.7e7 arguments incl. every k pi/2 up to 6e4 within 3e-7
+// relative: sincos_check in profiles/r4_sincos.txt; NumPy's own SIMD float32 loops are specified to <= 4 ulp); larger
+// arguments, infinities and NaN take OCML's routine. sin, cos and sincos share the routine, so sin(v) and cos(v) of a fused
+// backward pass are bit-identical to the eager kernels' (tests/test_lazy_fusion.py).
+MD_HD void md_sincos_small(float x, float *sn, float *cs) {
+  float j = __builtin_fmaf(x, 0.636619747f, 12582912.0f) - 12582912.0f;   // rint(x * 2 / pi)
+  float r = __builtin_fmaf(j, -1.57079601e+00f, x);
+  r = __builtin_fmaf(j, -3.13916473e-07f, r);
+  r = __builtin_fmaf(j, -5.39030253e-15f, r);
+  const int i = (int)j;
+  const float s = r * r;
+  float p = 2.86567956e-6f;
+  p = __builtin_fmaf(p, s, -1.98559923e-4f);
+  p = __builtin_fmaf(p, s, 8.33338592e-3f);
+  p = __builtin_fmaf(p, s, -1.66666672e-1f);
+  const float sp = __builtin_fmaf(p, __builtin_fmaf(r, s, 0.0f), r);      // sin(r); (r * s + 0: a -0 argument comes out as -0)
+  float q = 2.44677067e-5f;
+  q = __builtin_fmaf(q, s, -1.38877297e-3f);
+  q = __builtin_fmaf(q, s, 4.16666567e-2f);
+  q = __builtin_fmaf(q, s, -0.5f);
+  const float cp = __builtin_fmaf(q, s, 1.0f);       // cos(r)
+  float a = (i & 1) ? cp : sp, b = (i & 1) ? sp : cp;
+  a = (i & 2) ? -a : a;
+  b = ((i + 1) & 2) ? -b : b;
+  *sn = a;
+  *cs = b;
+}
+MD_HD void md_sincos(float x, float *s, float *c) {
+  if (__builtin_fabsf(x) <= 105615.0f) md_sincos_small(x, s, c);
+  else sincosf(x, s, c);   // (also NaN and the infinities: the comparison is false for them)
+}
 MD_HD void md_sincos(double x, double *s, double *c) { sincos(x, s, c); }
+MD_HD float md_sin(float x) { float s, c; md_sincos(x, &s, &c); return s; }
+MD_HD float md_cos(float x) { float s, c; md_sincos(x, &s, &c); return c; }
+MD_HD double md_sin(double x) { return sin(x); }
+MD_HD double md_cos(double x) { return cos(x); }
 #else
+MD_MATH1(sin, sinf, sin)
+MD_MATH1(cos, cosf, cos)
 MD_HD void md_sincos(float x, float *s, float *c) { *s = sinf(x); *c = cosf(x); }
 MD_HD void md_sincos(double x, double *s, double *c) { *s = sin(x); *c = cos(x); }
 #endif
+#undef MD_MATH1
 MD_HD float md_fmod(float a, float b) { return fmodf(a, b); }
 MD_HD double md_fmod(double a, double b) { return fmod(a, b); }
 MD_HD float md_pow(float a, float b) { return powf(a, b); }
@@ -276,10 +397,14 @@ struct BFloorDiv {
       return md_float_divmod(a, b, &m);
     } else {
       if (b == 0) return 0;
-      if (b == (T)-1) { using U = typename md_uint_of<T>::type; return (T)((U)0 - (U)a); }
-      T q = a / b;
-      if (((a > 0) != (b > 0)) && (q * b != a)) q -= 1;
-      return q;
+      if constexpr (md_is_unsigned<T>::value) {
+        return a / b;
+      } else {
+        if (b == (T)-1) { using U = typename md_uint_of<T>::type; return (T)((U)0 - (U)a); }
+        T q = a / b;
+        if (((a > 0) != (b > 0)) && (q * b != a)) q -= 1;
+        return q;
+      }
     }
   }
 };
@@ -291,10 +416,14 @@ struct BMod {
       return m;
     } else {
       if (b == 0) return 0;
-      if (b == (T)-1) return 0;
-      T r = a % b;
-      if (r != 0 && ((r < 0) != (b < 0))) r += b;
-      return r;
+      if constexpr (md_is_unsigned<T>::value) {
+        return a % b;
+      } else {
+        if (b == (T)-1) return 0;
+        T r = a % b;
+        if (r != 0 && ((r < 0) != (b < 0))) r += b;
+        return r;
+      }
     }
   }
 };
@@ -317,7 +446,9 @@ struct BPow {
       using U = typename md_uint_of<T>::type;
       if (b == 0) return 1;
       if (a == 1) return 1;
-      if (b < 0) return 0;
+      if constexpr (!md_is_unsigned<T>::value) {
+        if (b < 0) return 0;
+      }
       U base = (U)a, acc = 1;
       U e = (U)b;
       while (e) {
@@ -369,12 +500,14 @@ struct RProd {
 };
 template <class T> MD_HD T md_lowest() {
   if constexpr (md_is_float<T>::value) return (T)-INFINITY;
+  else if constexpr (md_is_unsigned<T>::value && sizeof(T) == 8) return (T)0;
   else if constexpr (sizeof(T) == 8) return (T)INT64_MIN;
   else if constexpr (sizeof(T) == 4) return (T)INT32_MIN;
   else return (T)0;
 }
 template <class T> MD_HD T md_highest() {
   if constexpr (md_is_float<T>::value) return (T)INFINITY;
+  else if constexpr (md_is_unsigned<T>::value && sizeof(T) == 8) return (T)~(uint64_t)0;
   else if constexpr (sizeof(T) == 8) return (T)INT64_MAX;
   else if constexpr (sizeof(T) == 4) return (T)INT32_MAX;
   else return (T)1;

@@ -37,6 +37,8 @@
   X(GEMM_STAMP, "gemm_stamp", 0, 'x')                  /* in-kernel clock stamps (diagnostic) */                                \
   X(GEMM_F64_MFMA, "gemm_f64_mfma", 1, 'x')                                                                                     \
   X(GEMM_SKINNY, "gemm_skinny", 1, 'x')                /* 0: thin products stay on the MFMA / generic kernels */                \
+  X(JIT_U, "jit_u", 0, 'x')                            /* vector groups per lane and trip of the generated streaming kernels (0: by form) */ \
+  X(JIT_BLOCKS, "jit_blocks", 0, 'x')                  /* blocks per CU of the generated EVAL kernels (0: by form) */                     \
   X(SWEEP_NB, "sweep_nb", 0, 'x')                      /* fused eval + column sum: row bands (0: by shape) */                   \
   X(SWEEP_RU, "sweep_ru", 0, 'x')                                                                                               \
   X(SWEEP_NT_STORE, "sweep_nt_store", 1, 'x')                                                                                   \

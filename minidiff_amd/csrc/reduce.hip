@@ -18,6 +18,7 @@
 //          gridDim.y into partials [split][n_out] + a finishing pass.
 //   generic : one lane per output, div/mod walk — small or oddly strided inputs.
 #include "md_hip.h"
+#include "md_narrow.h"
 
 extern "C" int mdhip_alloc(size_t, void **);
 extern "C" int mdhip_free(void *);
@@ -180,10 +181,12 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows_wave(MdRedPlan pl, con
 // kernel above without its plan — a lane strides the 16-B vectors of the whole grid, two in flight — and the ticket finish
 // (md_ticket.h, two-level: ~1000 blocks arrive). 24.0 -> 22.5 us on cfg4's 128 MiB against the general kernel: the plan's
 // 400-byte argument block and per-thread offset arithmetic cost 1.5 us of a 20-us stream (profiles/r3_reduce_lab.txt).
-template <class R, class Tacc, class Tdst, bool NT>
-__global__ void __launch_bounds__(MD_BLOCK) k_reduce_all(const Tacc *__restrict__ x, int64_t n, Tacc *partial, unsigned *tickets, Tdst *out) {
-  constexpr int V = 16 / sizeof(Tacc);
-  typedef MdVec<Tacc, V> Vec;
+// S: the array's storage type — the accumulator's own, or a storage-only dtype (int8 .. float16: 16 / sizeof(S) elements per 16-B
+// load, each converted to the accumulator type: sum(int8) reads ONE byte per element)
+template <class R, class Tacc, class Tdst, bool NT, class S = Tacc>
+__global__ void __launch_bounds__(MD_BLOCK) k_reduce_all(const S *__restrict__ x, int64_t n, Tacc *partial, unsigned *tickets, Tdst *out) {
+  constexpr int V = 16 / sizeof(S);
+  typedef MdVec<S, V> Vec;
   __shared__ Tacc smem[MD_BLOCK / 64];
   __shared__ unsigned last_flag;
   const int64_t gs = (int64_t)gridDim.x * MD_BLOCK, gid = (int64_t)blockIdx.x * MD_BLOCK + threadIdx.x;
@@ -196,17 +199,17 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_all(const Tacc *__restrict_
   for (; i + gs < nvec; i += 2 * gs) {
     const Vec t = md_ld_once<NT>(pv + i), u = md_ld_once<NT>(pv + i + gs);
 #pragma unroll
-    for (int j = 0; j < V; ++j) { a2[j] = R::combine(a2[j], t.v[j]); a3[j] = R::combine(a3[j], u.v[j]); }
+    for (int j = 0; j < V; ++j) { a2[j] = R::combine(a2[j], md_cast<Tacc>(t.v[j])); a3[j] = R::combine(a3[j], md_cast<Tacc>(u.v[j])); }
   }
   if (i < nvec) {
     const Vec t = pv[i];
 #pragma unroll
-    for (int j = 0; j < V; ++j) a2[j] = R::combine(a2[j], t.v[j]);
+    for (int j = 0; j < V; ++j) a2[j] = R::combine(a2[j], md_cast<Tacc>(t.v[j]));
   }
   Tacc acc = R::template identity<Tacc>();
 #pragma unroll
   for (int j = 0; j < V; ++j) acc = R::combine(acc, R::combine(a2[j], a3[j]));
-  if (nvec * V + gid < n) acc = R::combine(acc, x[nvec * V + gid]);  // the up-to-(V-1) elements behind the last whole vector
+  if (nvec * V + gid < n) acc = R::combine(acc, md_cast<Tacc>(x[nvec * V + gid]));  // the up-to-(V-1) elements behind the last whole vector
   acc = md_block_reduce<R>(acc, smem);
   if (threadIdx.x == 0) md_st_sc1(partial + blockIdx.x, acc);
   const bool last = gridDim.x >= 64 ? md_ticket_last2(tickets, blockIdx.x, gridDim.x, &last_flag) : md_ticket_last(tickets, gridDim.x, &last_flag);
@@ -1024,6 +1027,28 @@ struct HipExec {
       int rc;
       if constexpr (sizeof(Tacc) >= 4) {
         const bool all_on = md_opt(MD_OPT_REDUCE_ALL) != 0;  // 0: the general rows kernel (A/B)
+        // the whole of a contiguous array of a STORAGE-ONLY dtype (sum(int8), max(float16) ..): the same kernel, 16-B loads of the narrow type
+        if (all_on && n_out == 1 && pl.nr == 1 && pl.rx[0] == 1 && md_is_narrow(x->dtype) && ((uintptr_t)x->data & 15) == 0) {
+#define MD_RED_ALL_AS(DT, S)                                                                                                          \
+          if (x->dtype == DT) {                                                                                                        \
+            if (nt) MD_LAUNCH((k_reduce_all<R, Tacc, To, true, S>), (unsigned)splits, MD_BLOCK, (const S *)x->data, n_red, (Tacc *)partial, md_tickets(), (To *)out->data); \
+            else MD_LAUNCH((k_reduce_all<R, Tacc, To, false, S>), (unsigned)splits, MD_BLOCK, (const S *)x->data, n_red, (Tacc *)partial, md_tickets(), (To *)out->data);   \
+            rc = MD_LAUNCH_CHECK("reduce(all, storage-only dtype)");                                                                   \
+            mdhip_free(partial);                                                                                                       \
+            return rc;                                                                                                                 \
+          }
+          // (only the accumulator types a storage-only input can meet: md_dispatch.h)
+          if constexpr (md_same<Tacc, int64_t>::value && (md_same<R, RSum>::value || md_same<R, RProd>::value)) {
+            MD_RED_ALL_AS(MDHIP_I8, int8_t) MD_RED_ALL_AS(MDHIP_I16, int16_t) MD_RED_ALL_AS(MDHIP_U8, uint8_t) MD_RED_ALL_AS(MDHIP_U16, uint16_t)
+            MD_RED_ALL_AS(MDHIP_U32, uint32_t) MD_RED_ALL_AS(MDHIP_U64, uint64_t)
+          }
+          if constexpr (md_same<Tacc, int32_t>::value && (md_same<R, RMax>::value || md_same<R, RMin>::value)) {
+            MD_RED_ALL_AS(MDHIP_I8, int8_t) MD_RED_ALL_AS(MDHIP_I16, int16_t) MD_RED_ALL_AS(MDHIP_U8, uint8_t) MD_RED_ALL_AS(MDHIP_U16, uint16_t)
+          }
+          if constexpr (md_same<Tacc, int64_t>::value && (md_same<R, RMax>::value || md_same<R, RMin>::value)) { MD_RED_ALL_AS(MDHIP_U32, uint32_t) }
+          if constexpr (md_same<Tacc, float>::value) { MD_RED_ALL_AS(MDHIP_F16, f16) }
+#undef MD_RED_ALL_AS
+        }
         if (all_on && n_out == 1 && pl.nr == 1 && pl.rx[0] == 1 && x->dtype == md_dtype_of<Tacc>::value && ((uintptr_t)x->data & 15) == 0) {
           if (nt) MD_LAUNCH((k_reduce_all<R, Tacc, To, true>), (unsigned)splits, MD_BLOCK, (const Tacc *)x->data, n_red, (Tacc *)partial, md_tickets(), (To *)out->data);
           else MD_LAUNCH((k_reduce_all<R, Tacc, To, false>), (unsigned)splits, MD_BLOCK, (const Tacc *)x->data, n_red, (Tacc *)partial, md_tickets(), (To *)out->data);
@@ -1144,5 +1169,5 @@ struct HipExec {
 }  // namespace
 
 extern "C" int mdhip_reduce(int op, const mdhip_array *x, const mdhip_array *out, uint32_t mask) {
-  return md_reduce_dispatch<HipExec>(op, x, out, mask);
+  return md_reduce_any_out<HipExec>(op, x, out, mask);   // (storage-only input dtypes load through md_load; storage-only results: md_narrow.h)
 }

@@ -2,7 +2,10 @@
 (minidiff/backend/numpy.py:188-200) beyond the five the kernels compute in.
 
 Arrays of these types live in device memory like any other (views, transfers, `astype`, strided copies: one conversion
-kernel, `mdhip_convert`). Arithmetic on them is
+kernel, `mdhip_convert`). Elementwise arithmetic, `where` / `clip` and the reductions on them run NATIVELY since round 4 —
+one launch that loads each operand in its own type, computes in the loop dtype's carrier (int32 / int64 / uint64 /
+float32: csrc/md_narrow.h) and stores in the result's type, 1.0x the algorithmic traffic. The functions listed in COMPUTE
+below still go
 
     promote to a wide device type  ->  the ordinary kernel  ->  demote to NumPy's result dtype
 
@@ -12,8 +15,9 @@ the truncating conversion; comparisons, divisions and reductions see the true va
 exception it raises for a combination it rejects) comes from running the SAME NumPy function on one-element host
 dummies of the operands' dtypes — no promotion table restated here.
 
-uint64 rides in int64 with the same bits: every function that looks at VALUES (not just bits) first checks that no
-element is >= 2**63 and raises TypeError otherwise — loud, not wrong.
+In the promote path uint64 rides in int64 with the same bits: a wrapped function that looks at VALUES (not just bits)
+first checks that no element is >= 2**63 and raises TypeError otherwise — loud, not wrong. (The native path has unsigned
+64-bit loops of its own: the whole range.)
 
 Nothing on a BASELINE path uses these types; the cost on the wide paths is one flag test per call (`install`)."""
 from __future__ import annotations
@@ -35,11 +39,12 @@ _MOVERS = {"concatenate", "stack", "tile", "repeat", "split", "getitem", "setite
 _INPLACE = {"setitem": 0, "index_add": 0, "put_along_axis": 0}
 _NP_NAME = {"index_add": None, "getitem": None, "setitem": None, "max": "max", "min": "min"}
 
+# Functions whose C entry points take the storage-only dtypes DIRECTLY (one launch, each operand read in its own type, the result
+# written in its own: csrc/narrow.hip, the 12-dtype loads of the reduction kernels) — every elementwise ufunc, where / clip and the
+# reductions — are NOT wrapped. What is wrapped below (promote -> wide kernel -> demote) are the functions that have no kernel for
+# these types yet: products, gathers / scatters by index arrays, the composed statistics, the array builders.
 COMPUTE = [
-    "absolute", "negative", "sign", "ceil", "floor", "sin", "cos", "tan", "sinh", "cosh", "tanh", "exp", "log", "sqrt",
-    "logical_not", "invert", "isnan", "add", "subtract", "multiply", "true_divide", "floor_divide", "mod", "power", "maximum",
-    "minimum", "equal", "not_equal", "less", "less_equal", "greater", "greater_equal", "logical_and", "logical_or", "logical_xor",
-    "where", "clip", "sum", "prod", "max", "min", "any", "all", "argmax", "argmin", "mean", "std", "matmul", "dot", "tensordot",
+    "mean", "std", "matmul", "dot", "tensordot",
     "concatenate", "stack", "tile", "repeat", "split", "take_along_axis", "put_along_axis", "index_add", "isin", "getitem", "setitem",
     "nonzero", "flatnonzero", "argwhere",
 ]

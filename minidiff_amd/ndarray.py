@@ -685,9 +685,8 @@ class DeviceArray(_fp.ArrayBase if _fp is not None else object):
 
 
 def _inplace(ufunc, code, fn, a, b):
-    """a OP= b: the wide types take the in-place kernel; a storage-only dtype on either side goes promote -> compute -> convert back."""
-    if a._code >= _NARROW_MIN or _any_narrow((b,), None):
-        return _narrow_inplace(ufunc, fn, a, b)
+    """a OP= b: the in-place kernel (any of the twelve dtypes: one launch; a loop whose result dtype differs from a's — uint8 += int16
+    under same-kind casting — computes into a temporary and converts)."""
     return _binary(ufunc, code, a, b, out=a)
 
 
@@ -704,7 +703,8 @@ def _scalar_desc(value, code: int) -> ArrayDesc:
     if code in _FLOAT_CODES:
         d.scalar_f = float(value)
     else:
-        d.scalar_i = int(value)
+        v = int(value)
+        d.scalar_i = v - (1 << 64) if v > _INT64_MAX else v     # (a uint64 value >= 2**63: same bits)
     return d
 
 
@@ -819,7 +819,10 @@ def _operand_desc(x, shape, code_for_scalar) -> ArrayDesc:
     if isinstance(x, DeviceArray):
         return x.desc(shape)
     if isinstance(x, np.generic):
-        return _scalar_desc(x.item(), dtype_code(x.dtype))
+        code = dtype_code(x.dtype)
+        if code >= _NARROW_MIN:     # a storage-only NumPy scalar travels as its VALUE (the loop dtype is passed separately)
+            code = _capi.F64 if x.dtype.kind == "f" else _capi.I64
+        return _scalar_desc(x.item(), code)
     return _scalar_desc(x, code_for_scalar)
 
 
@@ -827,16 +830,18 @@ _INT64_MIN, _INT64_MAX = -(2 ** 63), 2 ** 63 - 1
 
 
 def _scalar_code(x, loop_dt) -> int:
-    """dtype code under which a weak Python scalar travels to the kernel."""
+    """dtype code under which a weak Python scalar travels to the kernel (NEP 50: a Python int must FIT an integer loop dtype)."""
     if isinstance(x, float):
         return _capi.F64
     if isinstance(x, int) and not isinstance(x, py_bool):
-        if not (_INT64_MIN <= x <= _INT64_MAX):
+        if loop_dt.kind in "iu":
+            info = np.iinfo(loop_dt)
+            if not (info.min <= x <= info.max):
+                raise OverflowError(f"Python integer {x} out of bounds for {loop_dt}")
+        elif not (_INT64_MIN <= x <= _INT64_MAX):
             if loop_dt.kind == "f":
                 return _capi.F64
             raise OverflowError(f"Python integer {x} out of bounds for {loop_dt}")
-        if loop_dt.kind == "i" and loop_dt.itemsize == 4 and not (-(2 ** 31) <= x < 2 ** 31):
-            raise OverflowError(f"Python integer {x} out of bounds for int32")
     return _capi.I64
 
 
@@ -906,13 +911,9 @@ def _binary(ufunc, code, a, b, out=None):
         a_arr = True
     loop = _resolve(ufunc, (_kind_key(a), _kind_key(b)))
     cdt, odt = loop[0], loop[2]
-    if (cdt in _narrow._WIDE or odt in _narrow._WIDE) and out is None:
-        # NumPy resolves this pair to a storage-only loop (bool / bool -> float16, bool ** bool -> int8): the same arithmetic
-        # in the wide type, converted once (narrow.py)
-        wa = astype(a, _narrow._WIDE.get(loop[0], loop[0])) if a_arr else a
-        wb = astype(b, _narrow._WIDE.get(loop[1], loop[1])) if b_arr else b
-        res = _binary(ufunc, code, wa, wb)
-        return res if res.dtype == odt else _convert(res, odt)
+    # (a storage-only loop dtype — int8 * int8, float16 + float16, bool / bool -> float16 — or storage-only operands of a wide loop
+    # go to the same entry point: ONE launch that loads each operand in its own type and computes in the loop dtype's carrier,
+    # csrc/narrow.hip)
     if a_arr and b_arr:
         shape = _broadcast_shapes(a.shape, b.shape)
     else:
@@ -991,10 +992,7 @@ def _unary(ufunc, code, x):
         for dt in loop:
             dtype_code(dt)
         _RESOLVE_CACHE[key] = loop
-    if loop[1] in _narrow._WIDE or loop[0] in _narrow._WIDE:
-        # (sin(bool array): NumPy answers in float16 — computed in float32, rounded once, as NumPy's own half loops do)
-        res = _unary(ufunc, code, astype(x, _narrow._WIDE.get(loop[0], loop[0])))
-        return res if res.dtype == loop[1] else _convert(res, loop[1])
+    # (sin(bool array): NumPy answers in float16 — computed in float32, rounded once, as NumPy's own half loops do: csrc/narrow.hip)
     if _LAZY and code != _capi.U_INVERT and x.size > 0:
         pcdt = _FLOAT_DT.get(loop[0])
         if pcdt is not None and (loop[1] == loop[0] or loop[1] == np.bool_) and x.dtype.kind in "fb" or \
@@ -1649,6 +1647,8 @@ def _sum_dtype(a_dtype, dtype):
         return np.dtype(dtype)
     if a_dtype.kind in "bi":
         return np.dtype(np.int64)
+    if a_dtype.kind == "u":
+        return np.dtype(np.uint64)      # (NumPy: unsigned integers accumulate in the unsigned platform integer)
     return a_dtype
 
 

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../minidiff_amd/csrc/md_dispatch.h"
+#include "../../minidiff_amd/csrc/md_narrow.h"
 #include "../../minidiff_amd/csrc/md_vm.h"
 #include "../../minidiff_amd/csrc/md_rng.h"
 
@@ -77,6 +78,41 @@ struct HostExec {
       T va = a->is_scalar ? sa : md_load<T>(a->data, a->dtype, offs[1]);
       T vb = b->is_scalar ? sb : md_load<T>(b->data, b->dtype, offs[2]);
       o[offs[3]] = vc ? va : vb;
+    }
+    return MDHIP_OK;
+  }
+  // storage-only dtypes (md_narrow.h): the same generic loops with 12-dtype loads / stores
+  template <class F, class Tc> static int nunary(const MdIter &it, const mdhip_array *x, const mdhip_array *out) {
+    const Tc sx = x->is_scalar ? md_scalar_as<Tc>(x) : Tc();
+    int64_t offs[MD_MAX_OPS];
+    for (int64_t i = 0; i < it.total; ++i) {
+      md_iter_offsets(it, i, offs);
+      const Tc v = x->is_scalar ? sx : md_load<Tc>(x->data, x->dtype, offs[0]);
+      md_store_as(out->data, out->dtype, offs[1], F::apply(v));
+    }
+    return MDHIP_OK;
+  }
+  template <class F, class Tc> static int nbinary(const MdIter &it, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out) {
+    const Tc sa = a->is_scalar ? md_scalar_as<Tc>(a) : Tc(), sb = b->is_scalar ? md_scalar_as<Tc>(b) : Tc();
+    int64_t offs[MD_MAX_OPS];
+    for (int64_t i = 0; i < it.total; ++i) {
+      md_iter_offsets(it, i, offs);
+      const Tc va = a->is_scalar ? sa : md_load<Tc>(a->data, a->dtype, offs[0]);
+      const Tc vb = b->is_scalar ? sb : md_load<Tc>(b->data, b->dtype, offs[1]);
+      md_store_as(out->data, out->dtype, offs[2], F::apply(va, vb));
+    }
+    return MDHIP_OK;
+  }
+  template <class Tc> static int nwhere(const MdIter &it, const mdhip_array *c, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out) {
+    const uint8_t sc = c->is_scalar ? md_scalar_as<uint8_t>(c) : 0;
+    const Tc sa = a->is_scalar ? md_scalar_as<Tc>(a) : Tc(), sb = b->is_scalar ? md_scalar_as<Tc>(b) : Tc();
+    int64_t offs[MD_MAX_OPS];
+    for (int64_t i = 0; i < it.total; ++i) {
+      md_iter_offsets(it, i, offs);
+      const uint8_t vc = c->is_scalar ? sc : md_load<uint8_t>(c->data, c->dtype, offs[0]);
+      const Tc va = a->is_scalar ? sa : md_load<Tc>(a->data, a->dtype, offs[1]);
+      const Tc vb = b->is_scalar ? sb : md_load<Tc>(b->data, b->dtype, offs[2]);
+      md_store_as(out->data, out->dtype, offs[3], vc ? va : vb);
     }
     return MDHIP_OK;
   }
@@ -224,7 +260,11 @@ int mdhip_graph_end(void **g) { if (!g_host_capturing) return md_fail(MDHIP_ERUN
 int mdhip_graph_launch(void *) { return md_fail(MDHIP_ERUNTIME, "the CPU test double cannot replay graphs"); }
 int mdhip_graph_destroy(void *) { return MDHIP_OK; }
 
-int mdhip_unary(int op, const mdhip_array *x, const mdhip_array *out) { return md_unary_dispatch<HostExec>(op, x, out); }
+static inline bool narrow_arr(const mdhip_array *a) { return a && !a->is_scalar && md_is_narrow(a->dtype); }
+int mdhip_unary(int op, const mdhip_array *x, const mdhip_array *out) {
+  if (op != MDHIP_U_COPY && x && out && (narrow_arr(x) || narrow_arr(out))) return md_narrow_unary_dispatch<HostExec>(op, x, out);
+  return md_unary_dispatch<HostExec>(op, x, out);
+}
 int mdhip_convert(const mdhip_array *x, const mdhip_array *out) {
   MD_TRY(md_check_any_array(x, "convert x"));
   MD_TRY(md_check_any_array(out, "convert out"));
@@ -243,9 +283,11 @@ int mdhip_convert(const mdhip_array *x, const mdhip_array *out) {
   return MDHIP_OK;
 }
 int mdhip_binary(int op, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out, int cdt) {
+  if (a && b && out && (narrow_arr(a) || narrow_arr(b) || narrow_arr(out) || md_is_narrow(cdt))) return md_narrow_binary_dispatch<HostExec>(op, a, b, out, cdt);
   return md_binary_dispatch<HostExec>(op, a, b, out, cdt);
 }
 int mdhip_where(const mdhip_array *c, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out) {
+  if (c && a && b && out && (narrow_arr(c) || narrow_arr(a) || narrow_arr(b) || narrow_arr(out))) return md_narrow_where_dispatch<HostExec>(c, a, b, out);
   return md_where_dispatch<HostExec>(c, a, b, out);
 }
 int mdhip_fill(const mdhip_array *out, const mdhip_array *scalar) {
@@ -314,7 +356,7 @@ int mdhip_random_permutation(uint64_t seed, uint64_t offset, const mdhip_array *
   return MDHIP_OK;
 }
 int mdhip_reduce(int op, const mdhip_array *x, const mdhip_array *out, uint32_t mask) {
-  return md_reduce_dispatch<HostExec>(op, x, out, mask);
+  return md_reduce_any_out<HostExec>(op, x, out, mask);
 }
 // variance / std along one axis: NumPy's _var spelled out (mean by a true division, centred squares, division, sqrt), sequential sums.
 // Same covered forms as the product (so that both the fused call and the composed fallback get exercised on the CPU too).

@@ -155,17 +155,23 @@ def test_bench_distributed_path_on_one_gpu(on_gpu, comm, workload):
     root = os.path.dirname(HERE)
     env = dict(os.environ, MDHIP_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(prefix="mdhip_bench_"), "detail.json")
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                        "--workload", workload, "--size", "512", "--no-cpu-baseline", "--comm", comm],
+                        "--workload", workload, "--size", "512", "--no-cpu-baseline", "--comm", comm, "--detail", detail]
+                       + (["--allow-torch-comm"] if comm == "torch" else []),
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
+    head = json.load(open(detail))["head"]
     assert line["config"]["collective"] == ("rccl-direct" if comm == "rccl" else "rccl-torch"), line["config"]
+    assert line["config"]["rccl_ranks"] == (1 if comm == "rccl" else None)      # what ncclCommCount reports for the live communicator
     assert line["config"]["allreduce_bytes"] > 0 and line["value"] > 0
     # every sweep that ran through Python sent its collective(s) from inside backward(): pre-roll, 1 + 1 eager sweeps in front of
     # the capture, the capturing run itself (the K timed sweeps are graph-segment replays: no Python), ten single synchronised
     # sweeps and the detail pass of cfg4. The torch communicator has no asynchronous form, but is cut into segments all the same.
-    seg = line["config"]["graph_replay"]
+    seg = head["config"]["graph_replay"]
+    assert line["config"]["graph_replay"] is True and line["config"]["graph_segments"] == seg["segments"]
     # (cfg4 over RCCL: the weight-gradient panels + the join; the torch communicator has one synchronous all-reduce and no join)
     assert isinstance(seg, dict) and seg["segments"] >= 2 and seg["collective_calls"] >= (2 if comm == "rccl" else 1), seg
-    assert line["config"]["allreduce_overlapped_sweeps"] == line["preroll_sweeps"] + 1 + 1 + 1 + 10 + (3 if workload == "cfg4" else 0)
+    assert head["config"]["allreduce_overlapped_sweeps"] == head["preroll_sweeps"] + 1 + 1 + 1 + 10 + (3 if workload == "cfg4" else 0)

@@ -262,9 +262,11 @@ def test_sweep_signature_never_copies_arrays_to_the_host(engines, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_tensor_indexed_getitem_sweep_is_captured(engines):
-    """... and such a sweep (gather by a resident index tensor, scatter-add in the backward) is captured and replayed by SweepCache:
-    the signature no longer synchronises inside the capture."""
+def test_tensor_indexed_getitem_sweep_stays_eager_and_correct(engines):
+    """A sweep with a gather by a resident index tensor and its scatter-add backward under SweepCache on the GPU. Its index bounds
+    are checked synchronously (NumPy raises IndexError at the call: mdhip_gather / mdhip_scatter read a flag back), so such a sweep
+    is NOT capturable — before and after the signature change; what the change guarantees is that the signature itself adds no
+    device-to-host copy, and that the cache notices the failed capture once and keeps running the sweep eagerly with right results."""
     from minidiff_amd.graph import SweepCache
     hip, _ = engines
     rng = np.random.default_rng(11)
@@ -283,4 +285,4 @@ def test_tensor_indexed_getitem_sweep_is_captured(engines):
         for _ in range(5):
             out = cache.run(step)
             np.testing.assert_array_equal(out["gx"].as_numpy(), exp)
-        assert cache.stats["captured"] == 1 and cache.stats["replayed"] >= 2 and cache.stats["uncapturable"] == 0, cache.stats
+        assert cache.stats["uncapturable"] == 1 and cache.stats["captured"] == 0 and cache.stats["eager"] == 5, cache.stats

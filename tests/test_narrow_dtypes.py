@@ -1,7 +1,7 @@
 """Storage-only dtypes of the reference table (minidiff/backend/numpy.py:188-200: float16, int8/16, uint8/16/32/64) against
 NumPy on seeded inputs: result dtypes, integer results bit-exact (wrap-around included), float16 within its precision; views,
 transfers, conversions, gathers / scatters, in-place forms, creation functions. The reference-generated golden cases for
-these dtypes are in tests/golden (narrow_*); minidiff_amd/narrow.py has the design."""
+these dtypes are in tests/golden (narrow_*); csrc/md_narrow.h and minidiff_amd/narrow.py have the design."""
 import numpy as np
 import pytest
 
@@ -88,17 +88,149 @@ def test_narrow_dtype_gpu(lib, on_gpu, dt):
     _run(nd, dt)
 
 
-def test_uint64_upper_half_is_refused_loudly_where_values_matter(lib):
+def test_uint64_whole_range_in_the_native_path(lib):
+    """Elementwise arithmetic, comparisons, where and the reductions have unsigned 64-bit loops of their own (csrc/md_narrow.h: the
+    uint64 carrier): values >= 2**63 give NumPy's results. The functions that still go promote -> wide kernel -> demote
+    (narrow.COMPUTE: products, statistics, gathers by index arrays) carry uint64 in int64 and refuse such values loudly."""
     from minidiff_amd import ndarray as nd
-    big = np.array([1, 2 ** 63 + 5, 7], dtype=np.uint64)
-    d = nd.asarray(big)
+    big = np.array([1, 2 ** 63 + 5, 7, 2 ** 64 - 1, 2 ** 63], dtype=np.uint64)
+    oth = np.array([3, 2 ** 63 + 1, 2 ** 64 - 1, 2, 5], dtype=np.uint64)
+    d, o = nd.asarray(big), nd.asarray(oth)
     assert np.array_equal(d.get(), big) and np.array_equal(d[::-1].get(), big[::-1])       # storage, views: fine
     assert np.array_equal(nd.concatenate([d, d]).get(), np.concatenate([big, big]))         # movers: fine (bits)
     assert np.array_equal(d.astype(np.float64).get(), big.astype(np.float64))              # conversion kernel: true values
-    with pytest.raises(TypeError, match="uint64"):
-        nd.max(d)
-    with pytest.raises(TypeError, match="uint64"):
-        nd.add(d, d)
+    for name in ("add", "subtract", "multiply", "floor_divide", "mod", "maximum", "minimum", "less", "greater_equal", "equal", "power"):
+        with np.errstate(all="ignore"):
+            ref = getattr(np, name)(big, oth)
+        got = getattr(nd, name)(d, o)
+        assert got.dtype == ref.dtype and np.array_equal(got.get(), ref), name
+    assert np.array_equal(nd.add(d, 2 ** 63 + 9).get(), big + np.uint64(2 ** 63 + 9))      # a Python int beyond int64 in a uint64 loop
+    with pytest.raises(OverflowError):
+        nd.add(d, -1)                                                                       # NEP 50: must fit the loop dtype
+    for name in ("max", "min", "sum", "prod", "argmax", "argmin", "any", "all"):
+        with np.errstate(all="ignore"):
+            ref = getattr(np, name)(big)
+        got = getattr(nd, name)(d)
+        assert got.dtype == ref.dtype and np.array_equal(np.asarray(got.get()), ref), name
+    assert np.array_equal(nd.where(nd.greater(d, o), d, o).get(), np.where(big > oth, big, oth))
+    # uint64 with int64: NumPy's loop is float64 — each operand converted first, no detour through int64
+    i64 = np.array([2 ** 62, -1, 3, -(2 ** 62), 0], dtype=np.int64)
+    ref = big + i64
+    got = nd.add(d, nd.asarray(i64))
+    assert got.dtype == ref.dtype == np.float64 and np.array_equal(got.get(), ref)
+    for fn in (lambda: nd.mean(d), lambda: nd.matmul(d, d)):                                # still promoted: loud
+        with pytest.raises(TypeError, match="uint64"):
+            fn()
+
+
+NATIVE_CASES = [("multiply", np.int8, np.int8), ("add", np.uint8, np.uint8), ("subtract", np.int16, np.int16), ("less", np.uint16, np.uint16),
+                ("maximum", np.uint32, np.uint32), ("add", np.float16, np.float16), ("floor_divide", np.uint64, np.uint64),
+                ("add", np.int8, np.int32), ("true_divide", np.int8, np.int8), ("multiply", np.float16, np.float32)]
+
+
+@pytest.mark.parametrize("name,ta,tb", NATIVE_CASES, ids=lambda v: getattr(v, "__name__", str(v)))
+def test_native_narrow_calls_are_one_launch(lib, name, ta, tb, monkeypatch):
+    """arithmetic on a storage-only dtype is ONE C-ABI call (mdhip_binary / mdhip_unary / mdhip_reduce with the
+    narrow dtype codes) — no mdhip_convert before or after it, no wide temporaries."""
+    from minidiff_amd import ndarray as nd
+    rng = np.random.default_rng(5)
+    a, b = rng.integers(1, 100, 1000).astype(ta), rng.integers(1, 100, 1000).astype(tb)
+    da, db = nd.asarray(a), nd.asarray(b)
+    calls = {}
+
+    def counting(entry):
+        plain = getattr(lib, entry)
+
+        def f(*args):
+            calls[entry] = calls.get(entry, 0) + 1
+            return plain(*args)
+        return f
+
+    for entry in ("binary", "unary", "convert", "reduce", "where"):
+        monkeypatch.setattr(lib, entry, counting(entry))
+    with np.errstate(all="ignore"):
+        ref = getattr(np, name)(a, b)
+    got = getattr(nd, name)(da, db)
+    assert calls == {"binary": 1}, calls
+    assert got.dtype == ref.dtype
+    g = got.get()
+    assert np.array_equal(g, ref) if ref.dtype.kind != "f" else np.allclose(g, ref, rtol=2e-3)
+    calls.clear()
+    s = nd.sum(da)
+    m = nd.negative(da) if np.dtype(ta).kind != "u" else nd.absolute(da)
+    assert calls == {"reduce": 1, "unary": 1}, calls
+    with np.errstate(all="ignore"):
+        assert s.dtype == a.sum().dtype and np.allclose(float(s.get()), float(a.sum()), rtol=2e-3)
+        assert np.array_equal(m.get(), -a if np.dtype(ta).kind != "u" else np.abs(a))
+
+
+def _strided_and_mixed(nd):
+    """The generic narrow kernel: strided / broadcast operands and mixed storage types in one launch, bit-exact for integers."""
+    rng = np.random.default_rng(9)
+    for ta, tb in ((np.int8, np.uint8), (np.int16, np.int8), (np.uint16, np.uint32), (np.uint8, np.float16), (np.int8, np.int64), (np.float16, np.float64),
+                   (np.uint64, np.uint8), (np.bool_, np.int8)):
+        a = rng.integers(0, 2 if ta is np.bool_ else 120, (6, 8)).astype(ta)
+        b = rng.integers(1, 120, (8, 6)).astype(tb)
+        da, db = nd.asarray(a), nd.asarray(b)
+        for name in ("add", "subtract", "multiply", "floor_divide", "maximum", "less_equal", "not_equal"):
+            if ta is np.bool_ and name == "subtract":
+                continue
+            with np.errstate(all="ignore"):
+                ref = getattr(np, name)(a[::2, 1:], b.T[::2, 1:])
+                ref_b = getattr(np, name)(a, b[:, 0])
+            got = getattr(nd, name)(da[::2, 1:], db.T[::2, 1:])
+            got_b = getattr(nd, name)(da, db[:, 0])
+            for g, r in ((got, ref), (got_b, ref_b)):
+                assert g.dtype == r.dtype, (ta, tb, name, g.dtype, r.dtype)
+                assert np.array_equal(g.get(), r) if r.dtype.kind != "f" else np.allclose(g.get(), r, rtol=2e-3), (ta, tb, name)
+    # float16: a weak Python float is a float16 VALUE in the loop (0.1 -> 0.0999755859375)
+    h = rng.standard_normal(64).astype(np.float16)
+    dh = nd.asarray(h)
+    for name, s in (("add", 0.1), ("multiply", 1.1), ("subtract", 3), ("true_divide", 0.3), ("power", 2.0)):
+        ref, got = getattr(np, name)(h, s), getattr(nd, name)(dh, s)
+        assert got.dtype == np.float16 and np.array_equal(got.get().view(np.uint16), ref.view(np.uint16)), (name, s)
+    for name in ("sin", "exp", "sqrt", "tanh"):
+        with np.errstate(all="ignore"):
+            ref, got = getattr(np, name)(h), getattr(nd, name)(dh)
+        assert got.dtype == np.float16 and np.allclose(got.get().astype(np.float32), ref.astype(np.float32), rtol=2e-3, atol=1e-3, equal_nan=True), name
+    # in-place forms, incl. a loop whose result dtype differs from the destination's (same-kind cast back)
+    u8 = rng.integers(0, 200, 50).astype(np.uint8)
+    i16 = rng.integers(-300, 300, 50).astype(np.int16)
+    c = nd.asarray(u8).copy(); c += nd.asarray(u8); r = u8.copy(); r += u8
+    assert np.array_equal(c.get(), r)
+    c = nd.asarray(i16).copy(); c *= nd.asarray(u8); r = i16.copy(); r *= u8
+    assert np.array_equal(c.get(), r)
+    # large contiguous arrays: the streaming kernels (16 B per lane), every element width, odd lengths (vector tail)
+    for dt in NARROW:
+        n = 70001
+        a, b = rng.integers(1, 100, n).astype(dt), rng.integers(1, 100, n).astype(dt)
+        da, db = nd.asarray(a), nd.asarray(b)
+        for name in ("add", "multiply", "subtract", "greater", "mod", "minimum"):
+            with np.errstate(all="ignore"):
+                ref = getattr(np, name)(a, b)
+            got = getattr(nd, name)(da, db).get()
+            assert np.array_equal(got, ref) if ref.dtype.kind != "f" else np.allclose(got, ref, rtol=2e-3), (dt, name)
+        with np.errstate(all="ignore"):
+            assert np.array_equal(nd.multiply(da, 3).get(), a * 3) if np.dtype(dt).kind != "f" else np.allclose(nd.multiply(da, 3).get(), a * 3, rtol=2e-3)
+            assert np.array_equal(nd.subtract(100, da).get(), 100 - a) if np.dtype(dt).kind != "f" else np.allclose(nd.subtract(100, da).get(), 100 - a, rtol=2e-3)
+            assert np.array_equal(nd.negative(da).get(), -a) if np.dtype(dt).kind == "i" else True
+            for red in ("sum", "max", "min", "argmax", "any"):
+                ref, got = getattr(np, red)(a), getattr(nd, red)(da)
+                assert got.dtype == ref.dtype and np.allclose(float(got.get()), float(ref), rtol=2e-3), (dt, red)
+
+
+def test_narrow_strided_and_mixed_cpu(lib, on_gpu):
+    if on_gpu:
+        pytest.skip("other twin")
+    from minidiff_amd import ndarray as nd
+    _strided_and_mixed(nd)
+
+
+@gpu
+def test_narrow_strided_and_mixed_gpu(lib, on_gpu):
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    _strided_and_mixed(nd)
 
 
 def test_half_conversion_rounds_to_nearest_even(lib):
