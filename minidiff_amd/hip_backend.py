@@ -52,6 +52,13 @@ def _shape_of(size):
     return (int(size),) if _is_int(size) else tuple(int(s) for s in size)
 
 
+# vmap (the finite-difference checker's row map): rows from which the per-row kernel sequence is replayed from one captured hipGraph
+VMAP_REPLAY = True
+VMAP_REPLAY_MIN = 8
+VMAP_ROWS_PER_GRAPH = 64
+builtins_min = min
+
+
 class HipBackendTable:
     tensor_constructor = staticmethod(nd.array)
     tensor_class = DeviceArray
@@ -134,13 +141,65 @@ class HipBackendTable:
 
     @staticmethod
     def vmap(fun):
-        # map `fun` over axis 0 (numpy.py:110-122 does it with apply_along_axis);
-        # each slice is a device view, results are stacked on the device
-        def mapped(arr):
-            arr = nd.asarray(arr)
+        """Map `fun` over axis 0 (reference: minidiff/backend/numpy.py:110-122, np.apply_along_axis over the flattened rows; used by
+        the finite-difference checker, minidiff/utils.py:133). Every row runs the SAME kernel sequence on a row-shaped input, so from
+        VMAP_REPLAY_MIN rows on the sequence is captured ONCE as a hipGraph over a resident buffer of up to VMAP_ROWS_PER_GRAPH rows and
+        replayed per batch — one copy in, one hipGraphLaunch, one copy out per 64 rows instead of a Python trip through every op of
+        `fun` for every row.
+        The captured graph stays with the mapped function (the checker maps x + h and x - h with the same one). A `fun` that needs
+        the host (a synchronising call, data-dependent Python) cannot be captured and takes the row loop, as do builds that cannot
+        capture at all (the CPU test double)."""
+        state = {"sweep": None, "row": None, "res": None, "key": None, "failed": False}
+
+        def loop(arr):
             outs = [nd.asarray(fun(arr[i])) for i in range(arr.shape[0])]
             return nd.stack(outs, axis=0)
 
+        def mapped(arr):
+            arr = nd.asarray(arr)
+            n = arr.shape[0]
+            if n < VMAP_REPLAY_MIN or state["failed"] or not VMAP_REPLAY:
+                return loop(arr)
+            from .graph import CapturedSweep, can_capture
+            if not arr.is_c_contiguous:
+                arr = nd.copy(arr)
+            K = builtins_min(VMAP_ROWS_PER_GRAPH, n)
+            key = (arr.shape[1:], arr.dtype, K)
+            if state["key"] != key:
+                if state["sweep"] is not None:
+                    state["sweep"].close()
+                    state["sweep"] = None
+                if not can_capture():
+                    state["failed"] = True
+                    return loop(arr)
+                rows = nd.copy(arr[:K])                      # the resident row buffer: K rows per graph launch
+
+                def batch():
+                    outs = [nd.asarray(fun(rows[k])) for k in range(K)]
+                    res = nd.stack(outs, axis=0)
+                    nd.materialize(res)
+                    return res
+
+                try:
+                    nd.asarray(fun(rows[0]))                 # eager first: run-time compiled kernels, allocator growth
+                    sweep = CapturedSweep(batch, warmup=0)
+                except RuntimeError:                        # not capturable: a call inside `fun` has to synchronise
+                    state["failed"] = True
+                    return loop(arr)
+                state.update(sweep=sweep, row=rows, res=sweep.outputs, key=key)
+            sweep, rows, res = state["sweep"], state["row"], state["res"]
+            out = nd.DeviceArray.empty((n,) + tuple(res.shape[1:]), res.dtype)
+            lib = nd._lib()
+            row_bytes, res_bytes = arr.nbytes // n, res.nbytes // K
+            src, dst, rp, op = arr.ptr, out.ptr, rows.ptr, res.ptr
+            for i in range(0, n, K):                         # K rows in (one copy), one hipGraphLaunch, K results out (one copy)
+                k = builtins_min(K, n - i)
+                lib.d2d(rp, src + i * row_bytes, k * row_bytes)
+                sweep.replay()
+                lib.d2d(dst + i * res_bytes, op, k * res_bytes)
+            return out
+
+        mapped.state = state      # (tests: which path ran)
         return mapped
 
     put_along_axis = staticmethod(nd.put_along_axis)

@@ -920,7 +920,8 @@ def _binary(ufunc, code, a, b, out=None):
         shape = a.shape if a_arr else b.shape
     if code == _capi.B_POW and cdt.kind == "i" and _prod(shape) > 0:
         _check_int_power(b)      # (NumPy raises from inside its loop: an EMPTY result never meets the negative exponent)
-    if _LAZY and out is None:
+    if _LAZY and out is None and not ((a_arr and a._code >= _NARROW_MIN) or (b_arr and b._code >= _NARROW_MIN)):
+        # (storage-only operands are never leaves of a fused program: the interpreter and the generated kernels read the five compute dtypes)
         pcdt = _FLOAT_DT.get(cdt)
         if pcdt is None and cdt.kind == "b" and code >= _capi.B_LAND:
             # logical op on bool operands: join the program of a pending operand
@@ -993,7 +994,7 @@ def _unary(ufunc, code, x):
             dtype_code(dt)
         _RESOLVE_CACHE[key] = loop
     # (sin(bool array): NumPy answers in float16 — computed in float32, rounded once, as NumPy's own half loops do: csrc/narrow.hip)
-    if _LAZY and code != _capi.U_INVERT and x.size > 0:
+    if _LAZY and code != _capi.U_INVERT and x.size > 0 and x._code < _NARROW_MIN:
         pcdt = _FLOAT_DT.get(loop[0])
         if pcdt is not None and (loop[1] == loop[0] or loop[1] == np.bool_) and x.dtype.kind in "fb" or \
                 (pcdt is not None and x.dtype.kind == "i" and pcdt == _capi.F64):
@@ -1146,7 +1147,7 @@ def where(condition, x=None, y=None):
     shape = arrs[0].shape
     for v in arrs[1:]:
         shape = _broadcast_shapes(shape, v.shape)
-    if _LAZY and _prod(shape) > 0:
+    if _LAZY and _prod(shape) > 0 and not builtins_any(v._code >= _NARROW_MIN for v in arrs):
         pcdt = _FLOAT_DT.get(odt)
         if pcdt is not None:
             res = _lazy_node(_lz.WHERE, 0, (c, a, b), pcdt, shape, odt)

@@ -70,6 +70,20 @@ def _check_cfg4(dev, s_d, s_o, out_d, out_o, mode):
     assert _rel(s_d["W"].grad.as_numpy(), exp_W) < 1e-5, mode
     assert _rel(s_d["b"].grad.as_numpy(), exp_b) < 1e-6, mode
     assert _rel(out_d["out"].as_numpy(), np.where(m_d, z_d, 0).sum(dtype=np.float64)) < 1e-5
+    # (3) ... and they are tied to the ORACLE's gradients at the full 8192 x 4096 size: a flipped mask[i, j]
+    # moves column j of W.grad by row i of X and b.grad[j] by 1, so with the flips COUNTED per column
+    #     |W.grad_dev - W.grad_oracle|[k, j] <= 1e-5 max|W.grad| + flips[j] max|X|      |b.grad_dev - b.grad_oracle|[j] <= 1e-6 max|b.grad| + flips[j]
+    flips = disagree.sum(axis=0).astype(np.float64)
+    gW_d, gW_o = s_d["W"].grad.as_numpy().astype(np.float64), s_o["W"].grad.as_numpy().astype(np.float64)
+    gb_d, gb_o = s_d["b"].grad.as_numpy().astype(np.float64), s_o["b"].grad.as_numpy().astype(np.float64)
+    bound_W = 1e-5 * np.abs(gW_o).max() + flips[None, :] * float(np.abs(X).max())
+    bound_b = 1e-6 * np.abs(gb_o).max() + flips
+    assert (np.abs(gW_d - gW_o) <= bound_W).all(), (mode, int(flips.sum()), float((np.abs(gW_d - gW_o) - bound_W).max()))
+    assert (np.abs(gb_d - gb_o) <= bound_b).all(), (mode, int(flips.sum()))
+    # columns without a flip (all but a few tens of the 4096) agree outright
+    clean = flips == 0
+    assert clean.sum() >= 0.97 * clean.size
+    assert _rel(gW_d[:, clean], gW_o[:, clean]) < 1e-5 and _rel(gb_d[clean], gb_o[clean]) < 1e-6, mode
 
 
 def test_matmul_properties_4096(lib, on_gpu):

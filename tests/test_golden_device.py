@@ -19,6 +19,19 @@ def _engine(lib):
     return build_engine(HipBackendTable, "dev")
 
 
+@pytest.fixture
+def lazy_mode(request):
+    """`lazy` twins: the same golden cases with lazy fusion on (minidiff_amd/lazy.py: fused elementwise chains, deferred products,
+    owed column sums) — so the driver's own `-m gpu` run covers the fused path on the reference's vectors, not only builder logs."""
+    from minidiff_amd import ndarray as nd
+    prev = nd.set_lazy(request.param == "lazy")
+    yield request.param
+    nd.set_lazy(prev)
+
+
+MODES = pytest.mark.parametrize("lazy_mode", ["eager", "lazy"], indirect=True)
+
+
 def _case(lib, on_gpu, want_gpu, key):
     if want_gpu:
         assert on_gpu and lib.target == "hip:gfx950"
@@ -27,13 +40,15 @@ def _case(lib, on_gpu, want_gpu, key):
     gu.run_case_on(_engine(lib), key, exact=False)
 
 
+@MODES
 @pytest.mark.parametrize("key", gu.case_keys())
-def test_device_matches_reference_cpu(lib, on_gpu, key): _case(lib, on_gpu, False, key)
+def test_device_matches_reference_cpu(lib, on_gpu, key, lazy_mode): _case(lib, on_gpu, False, key)
 
 
 @gpu
+@MODES
 @pytest.mark.parametrize("key", gu.case_keys())
-def test_device_matches_reference_gpu(lib, on_gpu, key): _case(lib, on_gpu, True, key)
+def test_device_matches_reference_gpu(lib, on_gpu, key, lazy_mode): _case(lib, on_gpu, True, key)
 
 
 def _config(lib, on_gpu, want_gpu, name):
@@ -61,10 +76,12 @@ def _config(lib, on_gpu, want_gpu, name):
         assert a == b, (name, i, a, b)
 
 
+@MODES
 @pytest.mark.parametrize("name", CONFIGS)
-def test_device_config_cpu(lib, on_gpu, name): _config(lib, on_gpu, False, name)
+def test_device_config_cpu(lib, on_gpu, name, lazy_mode): _config(lib, on_gpu, False, name)
 
 
 @gpu
+@MODES
 @pytest.mark.parametrize("name", CONFIGS)
-def test_device_config_gpu(lib, on_gpu, name): _config(lib, on_gpu, True, name)
+def test_device_config_gpu(lib, on_gpu, name, lazy_mode): _config(lib, on_gpu, True, name)
