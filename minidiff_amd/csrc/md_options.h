@@ -43,12 +43,8 @@
   X(SWEEP_RU, "sweep_ru", 0, 'x')                                                                                               \
   X(SWEEP_NT_STORE, "sweep_nt_store", 1, 'x')                                                                                   \
   X(ROWS_WAVE, "rows_wave", 1, 'x')                                                                                             \
-  X(COLS_SWEEP, "cols_sweep", 1, 'x')                  /* 0: tiled column kernels (+ finish launch) instead of the strips */     \
   X(COLS_NB, "cols_nb", 0, 'x')                                                                                                 \
   X(ROWS_BLOCKS, "rows_blocks", 0, 'x')                /* blocks of a split row reduction (0: 1024) */                          \
-  X(REDUCE_ALL, "reduce_all", 1, 'x')                  /* 0: whole-array reductions on the general rows kernel */               \
-  X(ROWS_TICKET, "rows_ticket", 1, 'x')                /* 0: split rows finish in a second launch */                            \
-  X(ARG_STRIPS, "arg_strips", 1, 'x')                                                                                           \
   X(ARG_BLOCKS, "arg_blocks", 0, 'x')                  /* blocks of the strips arg-reduction (0: one per CU) */                 \
   X(GATHER_RUNS, "gather_runs", 1, 'x')                                                                                         \
   X(SCATTER_CENSUS, "scatter_census", 1, 'x')

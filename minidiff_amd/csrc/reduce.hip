@@ -918,7 +918,7 @@ struct HipExec {
         const bool vec_ok = pl.nk == 1 && pl.nr == 1 && pl.ko[0] == 1 && x->dtype == md_dtype_of<Tacc>::value &&
                             (n_out % V) == 0 && (pl.rx[0] % V) == 0 && ((uintptr_t)x->data & 15) == 0 &&
                             ((uintptr_t)out->data & 15) == 0 && n_red >= 16;
-        const int sweep_mode = (int)md_opt(MD_OPT_COLS_SWEEP);  // 0: the tiled kernel below (A/B)
+        constexpr int sweep_mode = 1;   // (the tiled kernels below serve what the strips form does not cover: narrow / ragged / short problems)
         const int nb_force = (int)md_opt(MD_OPT_COLS_NB);
         // (f64 / integer max and min keep the tiled kernel — their compare chain wants more waves per CU)
         constexpr bool cheap = md_same<R, RSum>::value || md_same<R, RProd>::value ||
@@ -1026,7 +1026,7 @@ struct HipExec {
       const bool nt = n_red * n_out * (int64_t)sizeof(Tacc) > ((int64_t)320 << 20);
       int rc;
       if constexpr (sizeof(Tacc) >= 4) {
-        const bool all_on = md_opt(MD_OPT_REDUCE_ALL) != 0;  // 0: the general rows kernel (A/B)
+        constexpr bool all_on = true;
         // the whole of a contiguous array of a STORAGE-ONLY dtype (sum(int8), max(float16) ..): the same kernel, 16-B loads of the narrow type
         if (all_on && n_out == 1 && pl.nr == 1 && pl.rx[0] == 1 && md_is_narrow(x->dtype) && ((uintptr_t)x->data & 15) == 0) {
 #define MD_RED_ALL_AS(DT, S)                                                                                                          \
@@ -1056,7 +1056,7 @@ struct HipExec {
           mdhip_free(partial);
           return rc;
         }
-        const bool ticket_on = md_opt(MD_OPT_ROWS_TICKET) != 0;  // 0: two launches (A/B)
+        constexpr bool ticket_on = true;   // (the two-launch form below: more outputs x splits than ticket words, 1-byte accumulators)
         if (ticket_on && n_out * (splits >= 64 ? MD_TICKET2_WORDS : MD_TICKET_PAD) <= MD_TICKET_WORDS) {
           if (nt) MD_LAUNCH((k_reduce_rows<R, Tacc, To, 2, true>), (unsigned)(n_out * splits), MD_BLOCK, pl, x->data, x->dtype, splits, (To *)out->data, (Tacc *)partial, md_tickets());
           else MD_LAUNCH((k_reduce_rows<R, Tacc, To, 2>), (unsigned)(n_out * splits), MD_BLOCK, pl, x->data, x->dtype, splits, (To *)out->data, (Tacc *)partial, md_tickets());
@@ -1087,7 +1087,7 @@ struct HipExec {
           (pl.rx[0] % V) == 0 && ((uintptr_t)x->data & 15) == 0 && pl.n_red >= 16) {
         const int64_t n_out = pl.n_out, n_red = pl.n_red;
         const int64_t bxv = ceil_div(n_out, 64 * V);
-        const bool strips_on = md_opt(MD_OPT_ARG_STRIPS) != 0;   // 0: the chunked kernel + finish pass (A/B)
+        constexpr bool strips_on = true;   // (the chunked kernel + finish pass below: more strips than ticket words, short columns)
         if (strips_on && n_red < (1ll << 31) && n_red >= 64 && bxv * MD_TICKET_PAD <= MD_TICKET_WORDS) {
           const int64_t NS = bxv;
           const int arg_blocks = md_opt(MD_OPT_ARG_BLOCKS) > 0 ? (int)md_opt(MD_OPT_ARG_BLOCKS) : MD_NUM_CUS;   // one block per CU, as the column sums (rocprofv3: 26.6 us against 38.0 with four per CU); the knob is for experiments

@@ -48,15 +48,15 @@ def main():
         for rnd in range(rounds):
             for cfg in CFGS:
                 if os.environ.get("GEMM_NBUF_AB"):
-                    opt("gemm_nbuf", 2 + cfg // 1000)
+                    opt("gemm_nbuf", 2 + (cfg // 1000) % 10)
                 if os.environ.get("GEMM_PEEL_AB"):
-                    opt("gemm_peel", cfg // 10000)
+                    opt("gemm_peel", (cfg // 10000) % 10)
                 if cfg % 100 == 99 or cfg == -1:
                     opt("gemm_cfg", -1)      # the library's own choice
                 else:
                     opt("gemm_cfg", cfg % 100)
                 if os.environ.get("GEMM_GLDS_AB"):
-                    opt("gemm_glds", cfg // 100)
+                    opt("gemm_glds", (cfg // 100) % 10)
                 combos = (("NN", A, B), ("NT", A, Bt.T), ("TN", At.T, B)) + ((("TT", At.T, Bt.T),) if os.environ.get("GEMM_TT") else ())
                 for tag, a, b in combos:
                     nd.matmul(a, b)  # warm
