@@ -144,7 +144,7 @@ __global__ void k_scatter_serial(mdhip_index_plan pl, int64_t total, T *dst, Val
     const T val = val_at<T>(v, s, pl, pos);
     if constexpr (MODE == MDHIP_SCATTER_ADD) {
       if constexpr (md_same<T, uint8_t>::value) dst[off] = (uint8_t)(dst[off] || val);
-      else dst[off] = BAdd::apply(dst[off], val);
+      else dst[off] = md_storage_add(dst[off], val);
     } else {
       dst[off] = val;
     }
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(MD_BLOCK) k_apply(mdhip_index_plan pl, const i
       int64_t lin = i;
       for (int d = pl.ndim - 1; d >= 0; --d) { int64_t e = pl.shape[d]; int64_t q = lin / e; pos[d] = lin - q * e; lin = q; }
       const T val = val_at<T>(v, s, pl, pos);
-      if constexpr (MODE == MDHIP_SCATTER_ADD) dst[offs[i]] = BAdd::apply(dst[offs[i]], val);
+      if constexpr (MODE == MDHIP_SCATTER_ADD) dst[offs[i]] = md_storage_add(dst[offs[i]], val);
       else dst[offs[i]] = val;
       done[i] = 1;
     } else {
@@ -560,7 +560,8 @@ static int scatter_ordered(const mdhip_index_plan *pl, int64_t total, void *dst,
   return rc;
 }
 
-template <class T>
+// SMALL: a 1- / 2-byte storage type — no atomics of that width and no row-vector path: the ordered kernels serve both modes
+template <class T, bool SMALL = false>
 static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, const mdhip_array *val, int mode, bool unique_rows) {
   hipStream_t st = md_stream();
   ValDesc v;
@@ -574,6 +575,10 @@ static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, c
     else k_scatter_serial<T, MDHIP_SCATTER_ADD><<<1, 64, 0, st>>>(*pl, total, (T *)dst, v, s);
     return MD_LAUNCH_CHECK("scatter(serial)");
   }
+  if constexpr (SMALL) {
+    if (mode == MDHIP_SCATTER_SET) return scatter_ordered<T, MDHIP_SCATTER_SET>(pl, total, dst, v, s);
+    return scatter_ordered<T, MDHIP_SCATTER_ADD>(pl, total, dst, v, s);
+  } else {
   int64_t L = 0, P = 0;
   const bool runs = run_geometry(pl, &L, &P);
   if (mode == MDHIP_SCATTER_SET) {
@@ -589,6 +594,7 @@ static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, c
   } else {
     if (runs) return scatter_runs<T, MDHIP_SCATTER_ADD>(pl, P, L, dst, v, s, unique_rows);
     return scatter_ordered<T, MDHIP_SCATTER_ADD>(pl, total, dst, v, s);
+  }
   }
 }
 
@@ -702,7 +708,7 @@ int mdhip_nonzero_fill(const mdhip_array *x, int64_t count, int64_t *out_flat) {
 
 int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const mdhip_array *out) {
   MD_TRY(md_check_plan(pl));
-  MD_TRY(md_check_array(out, "gather out"));
+  MD_TRY(md_check_any_array(out, "gather out"));   // (a mover: any of the twelve dtypes, by element size)
   if (out->ndim != pl->ndim) return md_fail(MDHIP_EVALUE, "gather: out ndim %d != plan ndim %d", out->ndim, pl->ndim);
   const int64_t total = md_plan_total(pl);
   if (total == 0) return MDHIP_OK;
@@ -740,6 +746,7 @@ int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const m
   } else
   switch (md_dtype_size(dtype)) {
     case 1: k_gather<uint8_t><<<grid, MD_BLOCK, 0, st>>>(*pl, total, (const uint8_t *)src, (uint8_t *)out->data, oit, (int *)flag); break;
+    case 2: k_gather<uint16_t><<<grid, MD_BLOCK, 0, st>>>(*pl, total, (const uint16_t *)src, (uint16_t *)out->data, oit, (int *)flag); break;
     case 4: k_gather<uint32_t><<<grid, MD_BLOCK, 0, st>>>(*pl, total, (const uint32_t *)src, (uint32_t *)out->data, oit, (int *)flag); break;
     case 8: k_gather<uint64_t><<<grid, MD_BLOCK, 0, st>>>(*pl, total, (const uint64_t *)src, (uint64_t *)out->data, oit, (int *)flag); break;
     default: mdhip_free(flag); return md_fail(MDHIP_ETYPE, "gather: bad dtype code %d", dtype);
@@ -755,7 +762,8 @@ int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const m
 
 int mdhip_scatter(const mdhip_index_plan *pl, void *dst, int dtype, const mdhip_array *val, int mode) {
   MD_TRY(md_check_plan(pl));
-  MD_TRY(md_check_array(val, "scatter val"));
+  if (!val) return md_fail(MDHIP_EVALUE, "scatter: null value");
+  if (!val->is_scalar) MD_TRY(md_check_any_array(val, "scatter val"));
   if (!val->is_scalar && val->dtype != dtype) return md_fail(MDHIP_ETYPE, "scatter: value dtype must match destination");
   if (!val->is_scalar && val->ndim != pl->ndim) return md_fail(MDHIP_EVALUE, "scatter: value ndim mismatch");
   if (mode != MDHIP_SCATTER_SET && mode != MDHIP_SCATTER_ADD) return md_fail(MDHIP_EVALUE, "scatter: bad mode %d", mode);
@@ -797,6 +805,13 @@ int mdhip_scatter(const mdhip_index_plan *pl, void *dst, int dtype, const mdhip_
     case MDHIP_I64: return scatter_typed<int64_t>(pl, total, dst, val, mode, unique_rows);
     case MDHIP_F32: return scatter_typed<float>(pl, total, dst, val, mode, unique_rows);
     case MDHIP_F64: return scatter_typed<double>(pl, total, dst, val, mode, unique_rows);
+    // storage-only dtypes in their own type: SET moves bytes; ADD wraps for the integers (uint32 / uint64 add as int32 / int64: the
+    // same bits, integer atomics) and rounds to float16 after every contribution, in index order — np.add.at on a half array
+    case MDHIP_U32: return scatter_typed<int32_t>(pl, total, dst, val, mode, unique_rows);
+    case MDHIP_U64: return scatter_typed<int64_t>(pl, total, dst, val, mode, unique_rows);
+    case MDHIP_I8: case MDHIP_U8: return scatter_typed<int8_t, true>(pl, total, dst, val, mode, false);
+    case MDHIP_I16: case MDHIP_U16: return scatter_typed<int16_t, true>(pl, total, dst, val, mode, false);
+    case MDHIP_F16: return scatter_typed<f16, true>(pl, total, dst, val, mode, false);
   }
   return md_fail(MDHIP_ETYPE, "scatter: bad dtype code %d", dtype);
 }

@@ -61,6 +61,7 @@ static inline const char *md_dtype_name(int dt) {
   return "?";
 }
 static inline bool md_dtype_is_float(int dt) { return dt == MDHIP_F32 || dt == MDHIP_F64; }
+static inline bool md_dtype_is_unsigned(int dt) { return dt == MDHIP_U8 || dt == MDHIP_U16 || dt == MDHIP_U32 || dt == MDHIP_U64; }
 
 template <class T> struct md_dtype_of;
 template <> struct md_dtype_of<b8> { static constexpr int value = MDHIP_BOOL; };
@@ -134,10 +135,12 @@ template <class R> MD_HD void md_store_as(void *p, int dtype, int64_t off, R v) 
 template <class To, class R> MD_HD To md_to_out(R r) { return md_cast<To>(r); }
 
 // scalar operand -> compute type
+// (a scalar descriptor of dtype MDHIP_U64 carries the BITS of a value >= 2**63 in scalar_i)
 template <class Tc> static inline Tc md_scalar_as(const mdhip_array *s) {
   if constexpr (md_same<Tc, uint8_t>::value) {
     return md_dtype_is_float(s->dtype) ? (uint8_t)(s->scalar_f != 0.0) : (uint8_t)(s->scalar_i != 0);
   } else {
+    if (s->dtype == MDHIP_U64) return md_cast<Tc>((uint64_t)s->scalar_i);
     return md_dtype_is_float(s->dtype) ? md_cast<Tc>(s->scalar_f) : md_cast<Tc>(s->scalar_i);
   }
 }

@@ -149,6 +149,22 @@ template <class X> int md_narrow_binary_dispatch(int op, const mdhip_array *a_in
     return md_fail(MDHIP_ETYPE, "binary: out dtype %s != loop dtype %s", md_dtype_name(odt), md_dtype_name(cdt));
   }
   if (cdt == MDHIP_BOOL && !is_log && !is_cmp) return md_fail(MDHIP_ETYPE, "bool loops take the wide entry point");
+  // uint64 against a SIGNED operand (NumPy's 'Qq->?' / 'qQ->?' comparison loops; a Python int against a uint64 array): compared
+  // mathematically — in 128 bits, where both ranges fit — instead of after a cast of one side to the other's type
+  const bool a_u64 = a->dtype == MDHIP_U64, b_u64 = b->dtype == MDHIP_U64;
+  // (a scalar operand counts as signed only when it IS negative: `u64_array < 5` keeps the uint64 stream kernel)
+  const bool a_sgn = md_dtype_is_int(a->dtype) && !md_dtype_is_unsigned(a->dtype) && !(a->is_scalar && a->scalar_i >= 0);
+  const bool b_sgn = md_dtype_is_int(b->dtype) && !md_dtype_is_unsigned(b->dtype) && !(b->is_scalar && b->scalar_i >= 0);
+  if (is_cmp && ((a_u64 && b_sgn) || (b_u64 && a_sgn))) {
+    switch (op) {
+      case MDHIP_B_EQ: return X::template nbinary<BEq, __int128>(it, a, b, out);
+      case MDHIP_B_NE: return X::template nbinary<BNe, __int128>(it, a, b, out);
+      case MDHIP_B_LT: return X::template nbinary<BLt, __int128>(it, a, b, out);
+      case MDHIP_B_LE: return X::template nbinary<BLe, __int128>(it, a, b, out);
+      case MDHIP_B_GT: return X::template nbinary<BGt, __int128>(it, a, b, out);
+      default: return X::template nbinary<BGe, __int128>(it, a, b, out);
+    }
+  }
   switch (op) {
 #define MD_NB_NUM(code, F) \
   case code: MD_CARRIER_NUM_SWITCH(cdt, T, return (X::template nbinary<F, T>(it, a, b, out)))

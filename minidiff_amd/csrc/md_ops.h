@@ -340,7 +340,8 @@ struct UIsnan {
 // ============================ binary ==========================================
 template <class T> struct md_uint_of {
   using type = typename md_cond<sizeof(T) == 8, uint64_t,
-               typename md_cond<sizeof(T) == 4, uint32_t, uint8_t>::type>::type;
+               typename md_cond<sizeof(T) == 4, uint32_t,
+               typename md_cond<sizeof(T) == 2, uint16_t, uint8_t>::type>::type>::type;
 };
 struct BAdd {
   template <class T> static MD_HD T apply(T a, T b) {
@@ -348,6 +349,11 @@ struct BAdd {
     else { using U = typename md_uint_of<T>::type; return (T)((U)a + (U)b); }
   }
 };
+// a += b in the array's own storage type (np.add.at): integers wrap, float16 rounds after EVERY addition
+template <class T> MD_HD T md_storage_add(T a, T b) {
+  if constexpr (md_same<T, f16>::value) return md_float_to_f16(md_f16_to_float(a) + md_f16_to_float(b));
+  else return BAdd::apply(a, b);
+}
 struct BSub {
   template <class T> static MD_HD T apply(T a, T b) {
     if constexpr (md_is_float<T>::value) return a - b;

@@ -4,7 +4,9 @@
 Arrays of these types live in device memory like any other (views, transfers, `astype`, strided copies: one conversion
 kernel, `mdhip_convert`). Elementwise arithmetic, `where` / `clip` and the reductions on them run NATIVELY since round 4 —
 one launch that loads each operand in its own type, computes in the loop dtype's carrier (int32 / int64 / uint64 /
-float32: csrc/md_narrow.h) and stores in the result's type, 1.0x the algorithmic traffic. The functions listed in COMPUTE
+float32: csrc/md_narrow.h) and stores in the result's type, 1.0x the algorithmic traffic — and so do the gathers / scatters
+by index arrays (csrc/index.hip: elements move by size; np.add.at wraps the integers and rounds float16 after every
+contribution, in index order, as NumPy's unbuffered loop does). The functions listed in COMPUTE
 below still go
 
     promote to a wide device type  ->  the ordinary kernel  ->  demote to NumPy's result dtype
@@ -17,7 +19,7 @@ dummies of the operands' dtypes — no promotion table restated here.
 
 In the promote path uint64 rides in int64 with the same bits: a wrapped function that looks at VALUES (not just bits)
 first checks that no element is >= 2**63 and raises TypeError otherwise — loud, not wrong. (The native path has unsigned
-64-bit loops of its own: the whole range.)
+64-bit loops of its own: the whole range; mean / std read uint64 as float64, NumPy's own first step.)
 
 Nothing on a BASELINE path uses these types; the cost on the wide paths is one flag test per call (`install`)."""
 from __future__ import annotations
@@ -34,19 +36,19 @@ _U64 = np.dtype(np.uint64)
 NARROW_CODE_MIN = 5   # _capi.I8: DeviceArray._code >= this <=> storage-only dtype
 
 # functions that move elements without looking at their values: uint64 needs no range check there
-_MOVERS = {"concatenate", "stack", "tile", "repeat", "split", "getitem", "setitem", "take_along_axis", "put_along_axis", "where_branches"}
-# in-place functions: index of the destination argument
-_INPLACE = {"setitem": 0, "index_add": 0, "put_along_axis": 0}
-_NP_NAME = {"index_add": None, "getitem": None, "setitem": None, "max": "max", "min": "min"}
+_MOVERS = {"concatenate", "stack", "tile", "repeat", "split"}
+# the statistics: NumPy's own first step is float64 (the sum runs in float64, each element converted first), so uint64 widens
+# straight to float64 there — the whole range, no detour through int64
+_STATS = {"mean", "std"}
 
 # Functions whose C entry points take the storage-only dtypes DIRECTLY (one launch, each operand read in its own type, the result
 # written in its own: csrc/narrow.hip, the 12-dtype loads of the reduction kernels) — every elementwise ufunc, where / clip and the
 # reductions — are NOT wrapped. What is wrapped below (promote -> wide kernel -> demote) are the functions that have no kernel for
-# these types yet: products, gathers / scatters by index arrays, the composed statistics, the array builders.
+# these types yet: products, the composed statistics, the array builders. (Gathers and scatters by index arrays — getitem, setitem,
+# index_add, take_/put_along_axis — move or add in the array's own type: csrc/index.hip.)
 COMPUTE = [
     "mean", "std", "matmul", "dot", "tensordot",
-    "concatenate", "stack", "tile", "repeat", "split", "take_along_axis", "put_along_axis", "index_add", "isin", "getitem", "setitem",
-    "nonzero", "flatnonzero", "argwhere",
+    "concatenate", "stack", "tile", "repeat", "split", "isin", "nonzero", "flatnonzero", "argwhere",
 ]
 
 
@@ -94,6 +96,8 @@ def install(ns: dict):
     def widen(x, name):
         if type(x) is DeviceArray:
             if x._code >= NARROW_CODE_MIN:
+                if x.dtype == _U64 and name in _STATS:
+                    return convert(x, np.dtype(np.float64))
                 w = convert(x, _WIDE[x.dtype])
                 if x.dtype == _U64 and name not in _MOVERS and x.size and bool(ns["any"](ns["less"](w, 0)).item()):
                     raise TypeError(f"uint64 values >= 2**63 are not supported by the MI355X backend in {name}()")
@@ -122,39 +126,8 @@ def install(ns: dict):
             return type(res)(demote(r, f) for r, f in zip(res, ref))
         return res
 
-    def basic_key(key) -> bool:
-        if not isinstance(key, tuple):
-            key = (key,)
-        for k in key:
-            if not (k is None or k is Ellipsis or isinstance(k, (int, slice, np.integer))):
-                return False
-        return True
-
-    def call_numpy(name, npf, dargs, dkw):
-        if name == "getitem":
-            return np.zeros((0,), dtype=dargs[0].dtype)
-        if name == "index_add":
-            np.add.at(dargs[0], dummy_key(dargs[1]), dargs[2] if len(dargs) > 2 else dkw.get("b"))
-            return None
-        if name == "setitem":
-            dargs[0][dummy_key(dargs[1])] = dargs[2]
-            return None
-        return npf(*dargs, **dkw)
-
-    def dummy_key(key):
-        """A key that is valid on a one-element dummy: same index ARRAYS (dtype rules), positions zeroed."""
-        def one(k):
-            if isinstance(k, np.ndarray):
-                return np.zeros_like(k) if k.dtype != np.bool_ else np.ones_like(k)
-            if isinstance(k, (list, tuple)):
-                return type(k)(one(x) for x in k)
-            if isinstance(k, (int, np.integer)):
-                return 0
-            return k
-        return tuple(one(k) for k in key) if isinstance(key, tuple) else one(key)
-
     def make(name, fn):
-        npf = getattr(np, _NP_NAME.get(name, name) or "zeros")
+        npf = getattr(np, name)
 
         def wrapped(*args, **kw):
             for x in args:                         # the common case inline: device arrays of the compute dtypes and Python scalars
@@ -169,24 +142,13 @@ def install(ns: dict):
             else:
                 if not kw or not any_narrow((), kw):
                     return fn(*args, **kw)
-            if name == "getitem" and basic_key(args[1]):
-                return fn(*args, **kw)          # a view: strides only, no kernel
             # NumPy's own verdict on dtypes (and its exceptions) from one-element dummies
             dargs = [dummy(a) for a in args]
             dkw = {k: dummy(v) for k, v in kw.items()}
-            if name in ("take_along_axis", "put_along_axis") and len(dargs) > 1 and isinstance(dargs[1], np.ndarray):
-                dargs[1] = np.zeros_like(dargs[1])      # positions must exist in a one-element dummy
             with np.errstate(all="ignore"):
-                ref = call_numpy(name, npf, dargs, dkw)
+                ref = npf(*dargs, **dkw)
             wargs = [widen(a, name) for a in args]
             wkw = {k: (_WIDE[np.dtype(v)] if k == "dtype" and v is not None and is_narrow_dtype(v) else widen(v, name)) for k, v in kw.items()}
-            dest = _INPLACE.get(name)
-            if dest is not None:
-                target = args[dest]
-                fn(*wargs, **wkw)
-                if type(target) is DeviceArray and target._code >= NARROW_CODE_MIN:
-                    ns["_copy_into"](target, wargs[dest])     # the widened copy was updated: back into the narrow array
-                return None
             return demote(fn(*wargs, **wkw), ref)
 
         wrapped.__name__ = getattr(fn, "__name__", name)

@@ -704,7 +704,10 @@ def _scalar_desc(value, code: int) -> ArrayDesc:
         d.scalar_f = float(value)
     else:
         v = int(value)
-        d.scalar_i = v - (1 << 64) if v > _INT64_MAX else v     # (a uint64 value >= 2**63: same bits)
+        if v > _INT64_MAX:      # a uint64 value >= 2**63 travels as its bits, under the uint64 code (md_scalar_as reads it unsigned)
+            d.dtype = _capi.U64
+            v -= 1 << 64
+        d.scalar_i = v
     return d
 
 
@@ -920,6 +923,12 @@ def _binary(ufunc, code, a, b, out=None):
         shape = a.shape if a_arr else b.shape
     if code == _capi.B_POW and cdt.kind == "i" and _prod(shape) > 0:
         _check_int_power(b)      # (NumPy raises from inside its loop: an EMPTY result never meets the negative exponent)
+    if _capi.B_EQ <= code <= _capi.B_GE and cdt.kind in "iu" and out is None:
+        # a Python int beyond the loop dtype's range compares as the number it is (NumPy 2: `u64_array >= -1` is all True,
+        # `i32_array == 2**40` all False) — the answer does not depend on the array's values
+        const = _oob_compare(code, a, b, cdt)
+        if const is not None:
+            return full(shape, const, dtype=np.bool_)
     if _LAZY and out is None and not ((a_arr and a._code >= _NARROW_MIN) or (b_arr and b._code >= _NARROW_MIN)):
         # (storage-only operands are never leaves of a fused program: the interpreter and the generated kernels read the five compute dtypes)
         pcdt = _FLOAT_DT.get(cdt)
@@ -961,6 +970,37 @@ def _binary(ufunc, code, a, b, out=None):
         _lib().binary(code, da, db, tmp.desc(), _DTYPE_CODES[cdt])
         _copy_into(out, tmp)
     return out
+
+
+def _oob_compare(code, a, b, cdt):
+    """The constant answer of `array CMP python_int` when the int lies outside cdt's range; None when it fits."""
+    for x, swapped in ((b, False), (a, True)):
+        if type(x) is int:
+            info = np.iinfo(cdt)
+            if info.min <= x <= info.max:
+                return None
+            above = x > info.max          # array < x everywhere (above) or array > x everywhere
+            if swapped:                   # `x CMP array`: the array is on the right
+                above = not above
+            if code == _capi.B_EQ:
+                return False
+            if code == _capi.B_NE:
+                return True
+            return above if code in (_capi.B_LT, _capi.B_LE) else not above
+    return None
+
+
+def _value_desc(v, dt) -> ArrayDesc:
+    """Scalar descriptor of a value assigned / added into an array of dtype `dt` (NEP 50: a Python int must fit `dt`)."""
+    if isinstance(v, np.generic):
+        v = v.item()
+    if isinstance(v, (float, complex)):
+        return _scalar_desc(v, _capi.F64)
+    if isinstance(v, int) and not isinstance(v, py_bool) and dt.kind in "iu":
+        info = np.iinfo(dt)
+        if not (info.min <= v <= info.max):
+            raise OverflowError(f"Python integer {v} out of bounds for {dt}")
+    return _scalar_desc(v, _capi.I64)
 
 
 def _straighten(x):
@@ -2367,10 +2407,8 @@ def _scatter(a: DeviceArray, key, value, mode):
         while v.ndim > len(out_shape) and v.shape[0] == 1:
             v = v._view(v._offset, v.shape[1:], v._strides[1:])
         vd = v.desc(out_shape)
-    elif isinstance(v, np.generic):
-        vd = _scalar_desc(v.item(), dtype_code(v.dtype))
     else:
-        vd = _scalar_desc(v, _capi.F64 if isinstance(v, float) else _capi.I64)
+        vd = _value_desc(v, a.dtype)
     if _prod(out_shape):
         _lib().scatter(plan, base_ptr, a._code, vd, mode)
     del keep
@@ -2449,10 +2487,8 @@ def put_along_axis(arr, indices, values, axis):
         if v.dtype != arr.dtype:
             v = astype(v, arr.dtype)
         vd = v.desc(shape)
-    elif isinstance(v, np.generic):
-        vd = _scalar_desc(v.item(), dtype_code(v.dtype))
     else:
-        vd = _scalar_desc(v, _capi.F64 if isinstance(v, float) else _capi.I64)
+        vd = _value_desc(v, arr.dtype)
     if _prod(shape):
         _lib().scatter(plan, arr.ptr, arr._code, vd, _capi.SCATTER_SET)
     del keep

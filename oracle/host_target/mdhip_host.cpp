@@ -452,7 +452,7 @@ int mdhip_matmul_bias_relu_sum(const mdhip_array *a, const mdhip_array *b, const
 
 int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const mdhip_array *out) {
   MD_TRY(md_check_plan(pl));
-  MD_TRY(md_check_array(out, "gather out"));
+  MD_TRY(md_check_any_array(out, "gather out"));
   if (out->ndim != pl->ndim) return md_fail(MDHIP_EVALUE, "gather: out ndim mismatch");
   size_t es = md_dtype_size(dtype);
   int64_t n = md_plan_total(pl), pos[MDHIP_MAX_NDIM];
@@ -468,7 +468,8 @@ int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const m
 }
 int mdhip_scatter(const mdhip_index_plan *pl, void *dst, int dtype, const mdhip_array *val, int mode) {
   MD_TRY(md_check_plan(pl));
-  MD_TRY(md_check_array(val, "scatter val"));
+  if (!val) return md_fail(MDHIP_EVALUE, "scatter: null value");
+  if (!val->is_scalar) MD_TRY(md_check_any_array(val, "scatter val"));
   if (!val->is_scalar && val->dtype != dtype) return md_fail(MDHIP_ETYPE, "scatter: value dtype must match destination");
   size_t es = md_dtype_size(dtype);
   int64_t n = md_plan_total(pl), pos[MDHIP_MAX_NDIM];
@@ -486,7 +487,7 @@ int mdhip_scatter(const mdhip_index_plan *pl, void *dst, int dtype, const mdhip_
   case code: {                                                                            \
     T v = val->is_scalar ? md_scalar_as<T>(val) : ((const T *)val->data)[vo];             \
     T *d = (T *)dst + off;                                                                \
-    if (mode == MDHIP_SCATTER_ADD) *d = BAdd::apply(*d, v); else *d = v;                  \
+    if (mode == MDHIP_SCATTER_ADD) *d = md_storage_add(*d, v); else *d = v;               \
   } break;
     switch (dtype) {
       case MDHIP_BOOL: {
@@ -498,6 +499,13 @@ int mdhip_scatter(const mdhip_index_plan *pl, void *dst, int dtype, const mdhip_
       MD_SC(MDHIP_I64, int64_t)
       MD_SC(MDHIP_F32, float)
       MD_SC(MDHIP_F64, double)
+      MD_SC(MDHIP_U32, int32_t)
+      MD_SC(MDHIP_U64, int64_t)
+      MD_SC(MDHIP_I8, int8_t)
+      MD_SC(MDHIP_U8, int8_t)
+      MD_SC(MDHIP_I16, int16_t)
+      MD_SC(MDHIP_U16, int16_t)
+      MD_SC(MDHIP_F16, f16)
     }
 #undef MD_SC
     (void)es;

@@ -2,7 +2,8 @@
 """Differential fuzzing of the device array library against NumPy: random shapes, dtypes, strided /
 transposed / broadcast views and argument forms for the elementwise, reduction, arg-reduction,
 indexing and matmul entry points. Integers / bools / indices must match bit for bit, floats within
-a few ulp-scaled tolerances.   python tests/fuzz_device.py [n_cases] [seed] [--big]
+a few ulp-scaled tolerances.   python tests/fuzz_device.py [n_cases] [seed] [--big] [--narrow]
+--narrow adds the storage-only dtypes (int8/16, uint8/16/32/64, float16) to the dtype pool (native kernels since round 4).
 Runs on whatever library the process binds (the GPU product by default; tests bind the CPU double)."""
 import os
 import sys
@@ -14,6 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from minidiff_amd import ndarray as nd  # noqa: E402
 
 DTYPES = [np.float32, np.float64, np.int64, np.int32, np.bool_]
+NARROW_DTYPES = [np.int8, np.int16, np.uint8, np.uint16, np.uint32, np.uint64, np.float16]
 
 
 def rand_array(rng, shape, dt):
@@ -25,6 +27,12 @@ def rand_array(rng, shape, dt):
         return a
     if np.dtype(dt).kind == "b":
         return rng.random(shape) < 0.5
+    if np.dtype(dt).kind == "u":
+        a = rng.integers(0, 19, shape).astype(dt)
+        if a.size and rng.random() < 0.2:            # the top of the range too (wrap-around, uint64 >= 2**63)
+            flat = a.reshape(-1)
+            flat[rng.integers(0, flat.size, builtins_max(1, flat.size // 20))] = np.iinfo(dt).max - int(rng.integers(0, 3))
+        return a
     return rng.integers(-9, 10, shape).astype(dt)
 
 
@@ -84,14 +92,14 @@ def close(got, exp, what):
     if exp.dtype.kind in "biu":
         assert np.array_equal(got, exp), f"{what}: integer/bool mismatch"
         return
-    tol = 3e-6 if exp.dtype == np.float32 else 1e-13
+    tol = 3e-6 if exp.dtype == np.float32 else 1.5e-3 if exp.dtype == np.float16 else 1e-13
     with np.errstate(all="ignore"):
         same_special = np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(np.isinf(got), np.isinf(exp))
         assert same_special, f"{what}: nan/inf pattern differs"
         fin = np.isfinite(exp)
         if fin.any():
             err = np.abs(got[fin].astype(np.float64) - exp[fin].astype(np.float64))
-            bound = tol * np.maximum(np.abs(exp[fin]).astype(np.float64), 1e-30) + tol * 1e-2
+            bound = tol * np.maximum(np.abs(exp[fin]).astype(np.float64), 1e-30) + tol * (1e-2 if exp.dtype != np.float16 else 1e-4)
             assert (err <= bound).all(), f"{what}: max rel err {(err / np.maximum(np.abs(exp[fin]), 1e-30)).max():.3e}"
         inf = np.isinf(exp)
         assert np.array_equal(got[inf], exp[inf]), f"{what}: inf sign"
@@ -190,7 +198,7 @@ def one_case(rng, big):
                 got, exp = np.asarray(got), np.asarray(exp)
                 assert got.shape == exp.shape and got.dtype == exp.dtype, f"{name} {h.shape} axis={axis}: {got.shape}/{got.dtype} vs {exp.shape}/{exp.dtype}"
                 scale = np.abs(h.astype(np.float64)).sum() + 1.0 if name != "prod" else np.abs(exp).max() + 1.0
-                tol = 2e-6 if h.dtype == np.float32 else 1e-13
+                tol = 2e-6 if h.dtype == np.float32 else 2e-3 if h.dtype == np.float16 else 1e-13
                 # a product's rounding error grows with the number of factors and depends on their order (tree here, pairwise
                 # blocks in NumPy): ~sqrt(n) ulp typically — 1e6 factors once missed a flat 50-ulp bound (seed 101 --big)
                 n_red = max(h.size // max(exp.size, 1), 1)
@@ -355,8 +363,9 @@ def one_case(rng, big):
                 ax = int(rng.integers(0, h.ndim))
                 got, exp = np.asarray(nd.std(nd.asarray(hh), axis=ax)), np.std(hh, axis=ax)
                 assert got.shape == exp.shape and got.dtype == exp.dtype
-                tol = 2e-5 if h.dtype == np.float32 else 1e-11
-                assert np.abs(got - exp).max() <= tol * (np.abs(hh).max() + 1.0), f"std {h.shape} ax={ax}"
+                # (float16: NumPy rounds every step of its five to half; the device computes them in float32 and rounds once)
+                tol = 2e-5 if h.dtype == np.float32 else 4e-3 if h.dtype == np.float16 else 1e-11
+                assert np.abs(got.astype(np.float64) - exp.astype(np.float64)).max() <= tol * (float(np.abs(hh).max()) + 1.0), f"std {h.shape} ax={ax}"
         elif kind == "astype":
             to = DTYPES[int(rng.integers(0, len(DTYPES)))]
             if h.dtype.kind == "f" and np.dtype(to).kind in "iu":
@@ -365,7 +374,9 @@ def one_case(rng, big):
             close(nd.astype(d, to), h.astype(to), f"astype {h.shape} {h.dtype}->{np.dtype(to)}")
 
 
-def main(n=2000, seed=0, big=False):
+def main(n=2000, seed=0, big=False, narrow=False):
+    if narrow and NARROW_DTYPES[0] not in DTYPES:
+        DTYPES.extend(NARROW_DTYPES)
     fails = 0
     for i in range(n):
         rng = np.random.default_rng([seed, i])
@@ -381,10 +392,10 @@ def main(n=2000, seed=0, big=False):
                 traceback.print_exc()
         if fails >= 25:
             break
-    print(f"fuzz: {n} cases, seed {seed}, big={big}: {fails} failures", flush=True)
+    print(f"fuzz: {n} cases, seed {seed}, big={big}, narrow={narrow}: {fails} failures", flush=True)
     return fails
 
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    sys.exit(1 if main(int(args[0]) if args else 2000, int(args[1]) if len(args) > 1 else 0, "--big" in sys.argv) else 0)
+    sys.exit(1 if main(int(args[0]) if args else 2000, int(args[1]) if len(args) > 1 else 0, "--big" in sys.argv, "--narrow" in sys.argv) else 0)

@@ -90,8 +90,9 @@ def test_narrow_dtype_gpu(lib, on_gpu, dt):
 
 def test_uint64_whole_range_in_the_native_path(lib):
     """Elementwise arithmetic, comparisons, where and the reductions have unsigned 64-bit loops of their own (csrc/md_narrow.h: the
-    uint64 carrier): values >= 2**63 give NumPy's results. The functions that still go promote -> wide kernel -> demote
-    (narrow.COMPUTE: products, statistics, gathers by index arrays) carry uint64 in int64 and refuse such values loudly."""
+    uint64 carrier): values >= 2**63 give NumPy's results; gathers / scatters move and add in the array's own type. The functions
+    that still go promote -> wide kernel -> demote (narrow.COMPUTE: products, statistics) carry uint64 in int64 and refuse such
+    values loudly."""
     from minidiff_amd import ndarray as nd
     big = np.array([1, 2 ** 63 + 5, 7, 2 ** 64 - 1, 2 ** 63], dtype=np.uint64)
     oth = np.array([3, 2 ** 63 + 1, 2 ** 64 - 1, 2, 5], dtype=np.uint64)
@@ -118,9 +119,10 @@ def test_uint64_whole_range_in_the_native_path(lib):
     ref = big + i64
     got = nd.add(d, nd.asarray(i64))
     assert got.dtype == ref.dtype == np.float64 and np.array_equal(got.get(), ref)
-    for fn in (lambda: nd.mean(d), lambda: nd.matmul(d, d)):                                # still promoted: loud
-        with pytest.raises(TypeError, match="uint64"):
-            fn()
+    for name in ("mean", "std"):                                                            # read as float64, NumPy's first step
+        assert np.array_equal(getattr(nd, name)(d).get(), getattr(np, name)(big)), name
+    with pytest.raises(TypeError, match="uint64"):                                          # still carried in int64: loud
+        nd.matmul(d, d)
 
 
 NATIVE_CASES = [("multiply", np.int8, np.int8), ("add", np.uint8, np.uint8), ("subtract", np.int16, np.int16), ("less", np.uint16, np.uint16),
@@ -231,6 +233,85 @@ def test_narrow_strided_and_mixed_gpu(lib, on_gpu):
     assert on_gpu
     from minidiff_amd import ndarray as nd
     _strided_and_mixed(nd)
+
+
+def _index_and_compare(nd):
+    """Gathers / scatters by index arrays in the storage-only types themselves (csrc/index.hip: no promote -> demote round trip),
+    sizes on both sides of the serial / ordered split; 64-bit comparisons across signedness; Python ints beyond the loop dtype."""
+    rng = np.random.default_rng(77)
+    for dt in NARROW:
+        kind = np.dtype(dt).kind
+        for n, m in ((40, 25), (3000, 9000)):
+            if kind == "f":
+                a = (rng.standard_normal((n, 3)) * 8).astype(dt)
+                v = (rng.standard_normal((m, 3)) * 8).astype(dt)
+            else:
+                info = np.iinfo(dt)
+                a = rng.integers(info.min, info.max, (n, 3), dtype=dt, endpoint=True)      # the whole range: uint64 >= 2**63 included
+                v = rng.integers(info.min, info.max, (m, 3), dtype=dt, endpoint=True)
+            idx = rng.integers(-n, n, m)                                                    # duplicates, negative indices
+            da, dv, di = nd.asarray(a), nd.asarray(v), nd.asarray(idx)
+            assert np.array_equal(da[di].get(), a[idx]), (dt, n, "getitem")
+            assert np.array_equal(da[di, 1].get(), a[idx, 1]), (dt, n, "getitem col")
+            c, r = da.copy(), a.copy()
+            c[di] = dv; r[idx] = v
+            assert np.array_equal(c.get(), r), (dt, n, "setitem")                            # duplicates: the LAST write wins
+            c, r = da.copy(), a.copy()
+            with np.errstate(all="ignore"):
+                nd.index_add(c, di, dv); np.add.at(r, idx, v)
+            # (integers wrap; float16 rounds after EVERY contribution, in index order — as NumPy's unbuffered loop does)
+            assert np.array_equal(c.get(), r, equal_nan=(kind == "f")), (dt, n, "index_add")
+            c, r = da.copy(), a.copy()
+            with np.errstate(all="ignore"):
+                # (a typed scalar: for a bare Python int against uint64, NumPy's ufunc.at detours through float64 and drops low bits)
+                nd.index_add(c, di, dt(3)); np.add.at(r, idx, dt(3))
+            assert np.array_equal(c.get(), r, equal_nan=(kind == "f")), (dt, n, "index_add scalar")
+            ai = rng.integers(0, n, (n, 3))
+            assert np.array_equal(nd.take_along_axis(da, nd.asarray(ai), 0).get(), np.take_along_axis(a, ai, 0)), (dt, n, "take_along_axis")
+            c, r = da.copy(), a.copy()
+            pi = np.argsort(rng.random((n, 3)), axis=0)[: n // 2]
+            nd.put_along_axis(c, nd.asarray(pi), dv[: n // 2], 0); np.put_along_axis(r, pi, v[: n // 2], 0)
+            assert np.array_equal(c.get(), r), (dt, n, "put_along_axis")
+        if kind in "iu":
+            info = np.iinfo(dt)
+            c = nd.asarray(np.zeros(4, dt))
+            for bad in (info.max + 1, info.min - 1):
+                with pytest.raises(OverflowError):
+                    c[nd.asarray(np.array([0, 1]))] = bad                                  # NEP 50: a Python int must fit
+            c[nd.asarray(np.array([0, 1]))] = info.max
+            assert c.get()[1] == info.max
+    # uint64 against signed operands: NumPy's 'Qq->?' loops compare the numbers, not the bits
+    u = np.array([0, 5, 2 ** 63 + 5, 2 ** 64 - 1, 7], dtype=np.uint64)
+    for sdt in (np.int64, np.int32, np.int8):
+        sv = np.array([-1, 5, 100, -128, 8]).astype(sdt)
+        for name in ("less", "less_equal", "greater", "greater_equal", "equal", "not_equal"):
+            for x, y in ((u, sv), (sv, u), (u, sdt(-3)), (sdt(-3), u), (u[:1], sv), (u, sv[:1])):
+                ref = getattr(np, name)(x, y)
+                got = getattr(nd, name)(nd.asarray(x) if isinstance(x, np.ndarray) else x, nd.asarray(y) if isinstance(y, np.ndarray) else y)
+                assert got.dtype == ref.dtype and np.array_equal(got.get(), ref), (sdt, name)
+    # a Python int outside the loop dtype's range: comparisons answer for the number it is (arithmetic raises OverflowError)
+    for arr in (u, np.array([1, -3, 7], dtype=np.int32), np.array([1, -3, 7], dtype=np.int8), np.array([1, -3], dtype=np.int64)):
+        d = nd.asarray(arr)
+        for py in (-1, -(2 ** 70), 2 ** 64 + 3, 2 ** 63, 2 ** 40, -129, 200, 5, 2 ** 63 + 5):
+            for name in ("less", "less_equal", "greater", "greater_equal", "equal", "not_equal"):
+                ref, ref_r = getattr(np, name)(arr, py), getattr(np, name)(py, arr)
+                got, got_r = getattr(nd, name)(d, py), getattr(nd, name)(py, d)
+                assert got.dtype == np.bool_ and np.array_equal(got.get(), ref), (arr.dtype, py, name)
+                assert np.array_equal(got_r.get(), ref_r), (arr.dtype, py, name, "swapped")
+
+
+def test_narrow_index_and_compare_cpu(lib, on_gpu):
+    if on_gpu:
+        pytest.skip("other twin")
+    from minidiff_amd import ndarray as nd
+    _index_and_compare(nd)
+
+
+@gpu
+def test_narrow_index_and_compare_gpu(lib, on_gpu):
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    _index_and_compare(nd)
 
 
 def test_half_conversion_rounds_to_nearest_even(lib):
