@@ -18,8 +18,9 @@ exception it raises for a combination it rejects) comes from running the SAME Nu
 dummies of the operands' dtypes — no promotion table restated here.
 
 In the promote path uint64 rides in int64 with the same bits: a wrapped function that looks at VALUES (not just bits)
-first checks that no element is >= 2**63 and raises TypeError otherwise — loud, not wrong. (The native path has unsigned
-64-bit loops of its own: the whole range; mean / std read uint64 as float64, NumPy's own first step.)
+first checks that no element is >= 2**63 and raises TypeError otherwise — loud, not wrong. Only `isin` still does: the
+products and the nonzero family give the same bits either way (_BITS), a call whose NumPy loop is float64 (uint64 @ int64,
+mean / std of integers) converts each element straight from its own type, and the native path has unsigned 64-bit loops.
 
 Nothing on a BASELINE path uses these types; the cost on the wide paths is one flag test per call (`install`)."""
 from __future__ import annotations
@@ -40,6 +41,9 @@ _MOVERS = {"concatenate", "stack", "tile", "repeat", "split"}
 # the statistics: NumPy's own first step is float64 (the sum runs in float64, each element converted first), so uint64 widens
 # straight to float64 there — the whole range, no detour through int64
 _STATS = {"mean", "std"}
+# functions whose integer results are the same BITS whether 64-bit operands are read signed or unsigned (sums of products wrap
+# mod 2**64 either way; "is it zero" does not look at the sign): uint64 rides in int64 with no range check there
+_BITS = {"matmul", "dot", "tensordot", "nonzero", "flatnonzero", "argwhere"}
 
 # Functions whose C entry points take the storage-only dtypes DIRECTLY (one launch, each operand read in its own type, the result
 # written in its own: csrc/narrow.hip, the 12-dtype loads of the reduction kernels) — every elementwise ufunc, where / clip and the
@@ -93,26 +97,32 @@ def install(ns: dict):
             return type(x)(dummy(y) for y in x)
         return x
 
-    def widen(x, name):
+    def widen(x, name, to_f64=False):
+        """`to_f64`: NumPy's loop for this call is float64 although the narrow operand is an integer (uint64 @ int64, mean of
+        uint64): each element is converted first — straight from its own type, the whole uint64 range."""
         if type(x) is DeviceArray:
             if x._code >= NARROW_CODE_MIN:
-                if x.dtype == _U64 and name in _STATS:
+                if to_f64 and x.dtype.kind in "iu":
                     return convert(x, np.dtype(np.float64))
                 w = convert(x, _WIDE[x.dtype])
-                if x.dtype == _U64 and name not in _MOVERS and x.size and bool(ns["any"](ns["less"](w, 0)).item()):
+                if x.dtype == _U64 and name not in _MOVERS and name not in _BITS and x.size and bool(ns["any"](ns["less"](w, 0)).item()):
                     raise TypeError(f"uint64 values >= 2**63 are not supported by the MI355X backend in {name}()")
                 return w
             return x
         if isinstance(x, np.generic) and x.dtype in _WIDE:
-            if x.dtype == _U64 and int(x) >= 1 << 63:
+            if to_f64 and x.dtype.kind in "iu":
+                return np.float64(x)
+            if x.dtype == _U64 and name not in _BITS and int(x) >= 1 << 63:
                 raise TypeError(f"uint64 values >= 2**63 are not supported by the MI355X backend in {name}()")
-            return _WIDE[x.dtype].type(x)
+            return np.asarray(x).astype(_WIDE[x.dtype])[()]      # (uint64 >= 2**63 under _BITS: the same bits)
         if isinstance(x, np.ndarray) and x.dtype in _WIDE:
-            if x.dtype == _U64 and name not in _MOVERS and x.size and int(x.max()) >= 1 << 63:
+            if to_f64 and x.dtype.kind in "iu":
+                return x.astype(np.float64)
+            if x.dtype == _U64 and name not in _MOVERS and name not in _BITS and x.size and int(x.max()) >= 1 << 63:
                 raise TypeError(f"uint64 values >= 2**63 are not supported by the MI355X backend in {name}()")
             return x.astype(_WIDE[x.dtype])
         if isinstance(x, (list, tuple)):
-            return type(x)(widen(y, name) for y in x)
+            return type(x)(widen(y, name, to_f64) for y in x)
         return x
 
     def demote(res, ref):
@@ -147,8 +157,9 @@ def install(ns: dict):
             dkw = {k: dummy(v) for k, v in kw.items()}
             with np.errstate(all="ignore"):
                 ref = npf(*dargs, **dkw)
-            wargs = [widen(a, name) for a in args]
-            wkw = {k: (_WIDE[np.dtype(v)] if k == "dtype" and v is not None and is_narrow_dtype(v) else widen(v, name)) for k, v in kw.items()}
+            f64 = (name in _STATS or name in _BITS) and isinstance(ref, (np.ndarray, np.generic)) and ref.dtype == np.float64
+            wargs = [widen(a, name, f64) for a in args]
+            wkw = {k: (_WIDE[np.dtype(v)] if k == "dtype" and v is not None and is_narrow_dtype(v) else widen(v, name, f64)) for k, v in kw.items()}
             return demote(fn(*wargs, **wkw), ref)
 
         wrapped.__name__ = getattr(fn, "__name__", name)

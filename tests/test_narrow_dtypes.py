@@ -121,8 +121,19 @@ def test_uint64_whole_range_in_the_native_path(lib):
     assert got.dtype == ref.dtype == np.float64 and np.array_equal(got.get(), ref)
     for name in ("mean", "std"):                                                            # read as float64, NumPy's first step
         assert np.array_equal(getattr(nd, name)(d).get(), getattr(np, name)(big)), name
-    with pytest.raises(TypeError, match="uint64"):                                          # still carried in int64: loud
-        nd.matmul(d, d)
+    # products: sums of products wrap mod 2**64 whichever way the bits are read; against a signed operand NumPy's loop is float64
+    m, k = big.reshape(5, 1) * np.uint64(3) + oth, oth.reshape(5, 1) + big
+    for x, y in ((m, k), (m, m.T.copy()), (big, oth), (m, np.arange(-2, 3, dtype=np.int64).reshape(5, 1)), (m.astype(np.float32), big)):
+        with np.errstate(all="ignore"):
+            ref = np.matmul(x, y)
+        got = nd.matmul(nd.asarray(x), nd.asarray(y))
+        assert got.dtype == ref.dtype, (x.dtype, y.dtype, got.dtype, ref.dtype)
+        assert np.array_equal(got.get(), ref) if ref.dtype.kind in "iu" else np.allclose(got.get(), ref, rtol=1e-6), (x.dtype, y.dtype)
+    assert np.array_equal(nd.tensordot(nd.asarray(m), nd.asarray(k.T.copy()), axes=1).get(), np.tensordot(m, k.T.copy(), axes=1))
+    z = big.copy(); z[2] = 0
+    assert all(np.array_equal(g.get(), r) for g, r in zip(nd.nonzero(nd.asarray(z)), np.nonzero(z)))
+    with pytest.raises(TypeError, match="uint64"):                                          # the one function that still looks: loud
+        nd.isin(d, o)
 
 
 NATIVE_CASES = [("multiply", np.int8, np.int8), ("add", np.uint8, np.uint8), ("subtract", np.int16, np.int16), ("less", np.uint16, np.uint16),
