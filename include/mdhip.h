@@ -294,7 +294,14 @@ enum { MDHIP_SCATTER_SET = 0, MDHIP_SCATTER_ADD = 1 };
 int mdhip_gather(const mdhip_index_plan *plan, const void *src, int dtype,
                  const mdhip_array *out);
 /* dst[offset(p)] (=|+=) val[p]; duplicates accumulate in p order for ADD (the
- * np.add.at contract), last p wins for SET. Out-of-range -> MDHIP_EINDEX. */
+ * np.add.at contract), last p wins for SET. Out-of-range -> MDHIP_EINDEX, before
+ * anything is written (both calls read the verdict back: they SYNCHRONISE).
+ * Between mdhip_graph_begin and _end neither call can synchronise, and a later
+ * replay may meet other indices: there the kernels skip out-of-range positions
+ * (gather) / write nothing at all (scatter), and MDHIP_EINDEX is returned ONCE by
+ * the next mdhip_sync or mdhip_d2h after the replay that met them. A scatter that
+ * needs host-driven rounds (element-wise duplicates, > 4096 positions, not whole
+ * rows) fails the capture with MDHIP_ERUNTIME instead. */
 int mdhip_scatter(const mdhip_index_plan *plan, void *dst, int dtype,
                   const mdhip_array *val, int mode);
 

@@ -112,7 +112,13 @@ struct ValDesc {
   const void *p;
   int is_scalar;
   int64_t strides[MDHIP_MAX_NDIM];
+  // CAPTURED scatters (no host read of the bounds verdict): the flag of the bounds pass; bit 0 set = some index is out of range,
+  // and every kernel that would write leaves at once — NumPy's "raises before touching the destination", minus the raise, which
+  // waits for the next synchronisation (md_sticky_check). nullptr outside a capture: the host has already looked.
+  const int *guard;
 };
+#define MD_SCATTER_GUARD(v) do { if ((v).guard && (*(v).guard & 1)) return; } while (0)
+__global__ void k_flag_to_sticky(const int *flag, int *sticky) { if (*flag & 1) *sticky = 1; }
 template <class T> __device__ __forceinline__ T val_at(const ValDesc &v, T s, const mdhip_index_plan &pl, const int64_t *pos) {
   if (v.is_scalar) return s;
   int64_t vo = 0;
@@ -123,6 +129,7 @@ template <class T> __device__ __forceinline__ T val_at(const ValDesc &v, T s, co
 // integer ADD: atomics are exact and order-independent
 template <class T>
 __global__ void __launch_bounds__(MD_BLOCK) k_scatter_add_int(mdhip_index_plan pl, int64_t total, T *dst, ValDesc v, T s) {
+  MD_SCATTER_GUARD(v);
   const int64_t gs = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
     int64_t pos[MDHIP_MAX_NDIM];
@@ -137,6 +144,7 @@ __global__ void __launch_bounds__(MD_BLOCK) k_scatter_add_int(mdhip_index_plan p
 template <class T, int MODE>
 __global__ void k_scatter_serial(mdhip_index_plan pl, int64_t total, T *dst, ValDesc v, T s) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  MD_SCATTER_GUARD(v);
   for (int64_t i = 0; i < total; ++i) {
     int64_t pos[MDHIP_MAX_NDIM];
     bool oob = false;
@@ -219,6 +227,7 @@ __global__ void __launch_bounds__(MD_BLOCK) k_run_offsets(mdhip_index_plan pl, i
 template <class T, int MODE>
 __global__ void __launch_bounds__(MD_BLOCK) k_run_apply(mdhip_index_plan pl, int64_t P, int64_t L, int64_t lo, int64_t unit, const uint64_t *__restrict__ keys,
                                                        const int64_t *__restrict__ ids, T *dst, ValDesc v, T s) {
+  MD_SCATTER_GUARD(v);
   const int64_t gs = (int64_t)gridDim.x * blockDim.x, total = P * L;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
     const int64_t q = i / L, c = i - q * L;
@@ -251,6 +260,7 @@ template <class T, int MODE>
 __global__ void __launch_bounds__(MD_BLOCK) k_run_apply_vec(mdhip_index_plan pl, int64_t P, int64_t L, int64_t lo, int64_t unit, const uint64_t *__restrict__ keys,
                                                            const int64_t *__restrict__ ids, T *dst, ValDesc v, T s) {
   constexpr int V = 16 / sizeof(T);
+  MD_SCATTER_GUARD(v);
   const int64_t Lv = L / V, gs = (int64_t)gridDim.x * blockDim.x, total = P * Lv;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
     const int64_t q = i / Lv, c = (i - q * Lv) * V;
@@ -534,6 +544,8 @@ static int scatter_runs(const mdhip_index_plan *pl, int64_t P, int64_t L, void *
 // order-preserving rounds (see k_bid / k_apply)
 template <class T, int MODE>
 static int scatter_ordered(const mdhip_index_plan *pl, int64_t total, void *dst, const ValDesc &v, T s) {
+  // (rounds = the largest multiplicity of a destination, found by reading a flag back per round: not recordable)
+  if (md_capturing()) return md_fail(MDHIP_ERUNTIME, "scatter: element-wise duplicates at this size need host-driven rounds and cannot be captured into a graph");
   hipStream_t st = md_stream();
   const int grid = md_grid_for(total);
   const int64_t nslots = total * 2 + 1;
@@ -562,9 +574,10 @@ static int scatter_ordered(const mdhip_index_plan *pl, int64_t total, void *dst,
 
 // SMALL: a 1- / 2-byte storage type — no atomics of that width and no row-vector path: the ordered kernels serve both modes
 template <class T, bool SMALL = false>
-static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, const mdhip_array *val, int mode, bool unique_rows) {
+static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, const mdhip_array *val, int mode, bool unique_rows, const int *guard) {
   hipStream_t st = md_stream();
   ValDesc v;
+  v.guard = guard;
   v.p = val->data;
   v.is_scalar = val->is_scalar;
   for (int d = 0; d < MDHIP_MAX_NDIM; ++d) v.strides[d] = (!val->is_scalar && d < pl->ndim) ? val->strides[d] : 0;
@@ -697,6 +710,9 @@ static int nz_dispatch(const mdhip_array *x, int64_t *count_out, int64_t *out_fl
 
 }  // namespace
 
+namespace {
+int scatter_by_dtype(const mdhip_index_plan *pl, int64_t total, void *dst, int dtype, const mdhip_array *val, int mode, bool unique_rows, const int *guard);
+}
 extern "C" {
 
 int mdhip_nonzero_count(const mdhip_array *x, int64_t *count_out) { return nz_dispatch(x, count_out, nullptr); }
@@ -715,10 +731,13 @@ int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const m
   MdIter oit;
   memset(&oit, 0, sizeof oit);
   for (int d = 0; d < pl->ndim; ++d) oit.strides[0][d] = out->strides[d];
-  void *flag = nullptr;
-  MD_TRY(mdhip_alloc(sizeof(int), &flag));
+  // Inside a capture the verdict cannot be read back (and a later replay may see other indices): the kernels — which skip an
+  // out-of-range position either way — set the library's sticky word instead, reported at the next synchronisation.
+  const bool captured = md_capturing();
+  void *flag = captured ? (void *)md_sticky() : nullptr;
+  if (!captured) MD_TRY(mdhip_alloc(sizeof(int), &flag));
   hipStream_t st = md_stream();
-  (void)hipMemsetAsync(flag, 0, sizeof(int), st);
+  if (!captured) (void)hipMemsetAsync(flag, 0, sizeof(int), st);
   const int grid = md_grid_for(total);
   // whole 16-B units when the innermost axis is a contiguous run on both sides
   const int es = (int)md_dtype_size(dtype);
@@ -749,9 +768,10 @@ int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const m
     case 2: k_gather<uint16_t><<<grid, MD_BLOCK, 0, st>>>(*pl, total, (const uint16_t *)src, (uint16_t *)out->data, oit, (int *)flag); break;
     case 4: k_gather<uint32_t><<<grid, MD_BLOCK, 0, st>>>(*pl, total, (const uint32_t *)src, (uint32_t *)out->data, oit, (int *)flag); break;
     case 8: k_gather<uint64_t><<<grid, MD_BLOCK, 0, st>>>(*pl, total, (const uint64_t *)src, (uint64_t *)out->data, oit, (int *)flag); break;
-    default: mdhip_free(flag); return md_fail(MDHIP_ETYPE, "gather: bad dtype code %d", dtype);
+    default: if (!captured) mdhip_free(flag); return md_fail(MDHIP_ETYPE, "gather: bad dtype code %d", dtype);
   }
   int rc = MD_LAUNCH_CHECK("gather");
+  if (captured) return rc;
   int bad = 0;
   if (rc == MDHIP_OK) rc = read_flag((int *)flag, &bad);  // NumPy raises IndexError synchronously
   mdhip_free(flag);
@@ -792,35 +812,49 @@ int mdhip_scatter(const mdhip_index_plan *pl, void *dst, int dtype, const mdhip_
       k_check_bounds<<<md_grid_for(total), MD_BLOCK, 0, md_stream()>>>(*pl, total, 1, (int *)flag);
     }
   }
-  int bits = 0;
-  int rc = read_flag((int *)flag, &bits);
-  mdhip_free(flag);
+  int bits = 0, rc = MDHIP_OK;
+  const bool captured = md_capturing();
+  const int *guard = nullptr;
+  if (captured) {
+    // no read-back inside a capture: the writing kernels look at the flag themselves (ValDesc::guard), the sticky word carries
+    // the verdict to the next synchronisation, and rows count as possibly repeated (bit 1 of the census is not known here)
+    k_flag_to_sticky<<<1, 1, 0, md_stream()>>>((const int *)flag, md_sticky());
+    guard = (const int *)flag;
+    bits = 2;
+  } else {
+    rc = read_flag((int *)flag, &bits);
+    mdhip_free(flag);
+  }
   const bool unique_rows = census != nullptr && (bits & 2) == 0;
   if (census) mdhip_free(census);
   if (rc != MDHIP_OK) return rc;
   if (bits & 1) return md_fail(MDHIP_EINDEX, "index is out of bounds for the indexed axis");
+  rc = scatter_by_dtype(pl, total, dst, dtype, val, mode, unique_rows, guard);
+  if (captured) mdhip_free(flag);   // (stream-ordered reuse: the graph's own pool keeps the block for later nodes of this capture)
+  return rc;
+}
+}  // extern "C"
+namespace {
+int scatter_by_dtype(const mdhip_index_plan *pl, int64_t total, void *dst, int dtype, const mdhip_array *val, int mode, bool unique_rows, const int *guard) {
   switch (dtype) {
-    case MDHIP_BOOL: return scatter_typed<uint8_t>(pl, total, dst, val, mode, unique_rows);
-    case MDHIP_I32: return scatter_typed<int32_t>(pl, total, dst, val, mode, unique_rows);
-    case MDHIP_I64: return scatter_typed<int64_t>(pl, total, dst, val, mode, unique_rows);
-    case MDHIP_F32: return scatter_typed<float>(pl, total, dst, val, mode, unique_rows);
-    case MDHIP_F64: return scatter_typed<double>(pl, total, dst, val, mode, unique_rows);
+    case MDHIP_BOOL: return scatter_typed<uint8_t>(pl, total, dst, val, mode, unique_rows, guard);
+    case MDHIP_I32: return scatter_typed<int32_t>(pl, total, dst, val, mode, unique_rows, guard);
+    case MDHIP_I64: return scatter_typed<int64_t>(pl, total, dst, val, mode, unique_rows, guard);
+    case MDHIP_F32: return scatter_typed<float>(pl, total, dst, val, mode, unique_rows, guard);
+    case MDHIP_F64: return scatter_typed<double>(pl, total, dst, val, mode, unique_rows, guard);
     // storage-only dtypes in their own type: SET moves bytes; ADD wraps for the integers (uint32 / uint64 add as int32 / int64: the
     // same bits, integer atomics) and rounds to float16 after every contribution, in index order — np.add.at on a half array
-    case MDHIP_U32: return scatter_typed<int32_t>(pl, total, dst, val, mode, unique_rows);
-    case MDHIP_U64: return scatter_typed<int64_t>(pl, total, dst, val, mode, unique_rows);
-    case MDHIP_I8: case MDHIP_U8: return scatter_typed<int8_t, true>(pl, total, dst, val, mode, false);
-    case MDHIP_I16: case MDHIP_U16: return scatter_typed<int16_t, true>(pl, total, dst, val, mode, false);
-    case MDHIP_F16: return scatter_typed<f16, true>(pl, total, dst, val, mode, false);
+    case MDHIP_U32: return scatter_typed<int32_t>(pl, total, dst, val, mode, unique_rows, guard);
+    case MDHIP_U64: return scatter_typed<int64_t>(pl, total, dst, val, mode, unique_rows, guard);
+    case MDHIP_I8: case MDHIP_U8: return scatter_typed<int8_t, true>(pl, total, dst, val, mode, false, guard);
+    case MDHIP_I16: case MDHIP_U16: return scatter_typed<int16_t, true>(pl, total, dst, val, mode, false, guard);
+    case MDHIP_F16: return scatter_typed<f16, true>(pl, total, dst, val, mode, false, guard);
   }
   return md_fail(MDHIP_ETYPE, "scatter: bad dtype code %d", dtype);
 }
 
-
 // ---- random permutation of 0..n-1 (opt-in device RNG, md_rng.h): sort the indices by a 64-bit Philox key each --------------------
 // (numpy.py:135-136 permutation / shuffle: the caller gathers with the result). The stable LSD radix sort above, 8 passes.
-}  // extern "C"
-namespace {
 __global__ void __launch_bounds__(MD_BLOCK) k_perm_keys(uint64_t *__restrict__ keys, int64_t *__restrict__ ids, int64_t n, uint64_t seed, uint64_t offset) {
   const int64_t gs = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gs) {

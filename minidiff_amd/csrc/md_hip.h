@@ -12,6 +12,9 @@ hipStream_t md_stream();
 struct MdGemm;
 int md_gemm_skinny(const MdGemm &g, int dtype);           // skinny.hip: thin products (matrix x vector ..); -1 = not applicable
 unsigned *md_tickets();                                   // MD_TICKET_WORDS zeroed counters (md_ticket.h)
+bool md_capturing();                                      // a stream capture is recording (mdhip_graph_begin .. _end)
+int *md_sticky();                                         // host-mapped word a CAPTURED gather / scatter sets on an out-of-bounds index
+int md_sticky_check();                                    // after a synchronisation: MDHIP_EINDEX (and clear) if a replay set it
 bool md_prof_take(hipEvent_t *start, hipEvent_t *stop);   // bench timing: events for the next main kernel (MD_LAUNCH, the GEMM launchers), if any were attached
 int md_hip_check(hipError_t e, const char *what);
 

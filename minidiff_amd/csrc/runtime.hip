@@ -38,6 +38,7 @@ struct State {
   int device = -1;
   hipStream_t stream = nullptr;
   unsigned *tickets = nullptr;                       // md_ticket.h
+  int *sticky = nullptr;                             // pinned, device-visible: deferred index-bounds verdict of replayed graphs
   std::map<size_t, std::vector<void *>> free_lists;  // rounded size -> blocks
   std::unordered_map<void *, size_t> live;           // ptr -> rounded size
   std::unordered_map<void *, Graph *> owner;         // blocks reserved for a graph (live or privately cached)
@@ -69,6 +70,17 @@ int release_cache_locked(State &s) {
 
 hipStream_t md_stream() { return S().stream; }
 unsigned *md_tickets() { return S().tickets; }
+bool md_capturing() { return S().capturing != nullptr; }
+int *md_sticky() { return S().sticky; }
+// A gather / scatter recorded into a graph cannot hand its bounds verdict back at the call (no synchronisation inside a capture,
+// and the indices of a later replay are not known yet): its kernels set this word instead — and write nothing out of bounds — and
+// the next call that waits for the stream anyway reports it, once.
+int md_sticky_check() {
+  int *w = S().sticky;
+  if (!w || !*(volatile int *)w) return MDHIP_OK;
+  *(volatile int *)w = 0;
+  return md_fail(MDHIP_EINDEX, "index is out of bounds for the indexed axis (found by a gather / scatter of a replayed graph; reported at this synchronisation)");
+}
 
 // events to attach to the next GEMM kernel (mdhip_event_attach_next)
 static thread_local hipEvent_t t_prof_start = nullptr, t_prof_stop = nullptr;
@@ -108,10 +120,16 @@ int mdhip_init(int device) {
   // counters of the single-launch split reductions (md_ticket.h): zero now, and zero again after every launch that uses them
   MD_TRY(md_hip_check(hipMalloc((void **)&s.tickets, MD_TICKET_WORDS * sizeof(unsigned)), "hipMalloc(tickets)"));
   int rc = md_hip_check(hipMemset(s.tickets, 0, MD_TICKET_WORDS * sizeof(unsigned)), "hipMemset(tickets)");
-  if (rc == MDHIP_OK) rc = md_hip_check(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate");
+  if (rc == MDHIP_OK) rc = md_hip_check(hipHostMalloc((void **)&s.sticky, 64, hipHostMallocMapped), "hipHostMalloc(sticky)");
+  if (rc == MDHIP_OK) {
+    *s.sticky = 0;
+    rc = md_hip_check(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate");
+  }
   if (rc != MDHIP_OK) {  // nothing half-initialised stays behind
     (void)hipFree(s.tickets);
     s.tickets = nullptr;
+    if (s.sticky) (void)hipHostFree(s.sticky);
+    s.sticky = nullptr;
     s.stream = nullptr;
     return rc;
   }
@@ -131,6 +149,8 @@ int mdhip_shutdown(void) {
   release_cache_locked(s);
   (void)hipFree(s.tickets);
   s.tickets = nullptr;
+  (void)hipHostFree(s.sticky);
+  s.sticky = nullptr;
   (void)hipStreamDestroy(s.stream);
   s.stream = nullptr;
   s.device = -1;
@@ -315,7 +335,8 @@ int mdhip_h2d(void *dst, const void *src, size_t n) {
 int mdhip_d2h(void *dst, const void *src, size_t n) {
   if (!n) return MDHIP_OK;
   MD_TRY(md_hip_check(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, md_stream()), "hipMemcpyAsync(D2H)"));
-  return md_hip_check(hipStreamSynchronize(md_stream()), "hipStreamSynchronize");
+  MD_TRY(md_hip_check(hipStreamSynchronize(md_stream()), "hipStreamSynchronize"));
+  return md_sticky_check();
 }
 int mdhip_d2d(void *dst, const void *src, size_t n) {
   if (!n) return MDHIP_OK;
@@ -327,7 +348,7 @@ int mdhip_sync(void) {
   if (rc == MDHIP_OK) rc = md_hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
   // a kernel that died mid-way may have left a count behind: the next split reduction must start from zero
   if (rc != MDHIP_OK) (void)hipMemsetAsync(S().tickets, 0, MD_TICKET_WORDS * sizeof(unsigned), md_stream());
-  return rc;
+  return rc == MDHIP_OK ? md_sticky_check() : rc;
 }
 
 int mdhip_event_create(void **ev) {

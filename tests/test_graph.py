@@ -262,11 +262,12 @@ def test_sweep_signature_never_copies_arrays_to_the_host(engines, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_tensor_indexed_getitem_sweep_stays_eager_and_correct(engines):
-    """A sweep with a gather by a resident index tensor and its scatter-add backward under SweepCache on the GPU. Its index bounds
-    are checked synchronously (NumPy raises IndexError at the call: mdhip_gather / mdhip_scatter read a flag back), so such a sweep
-    is NOT capturable — before and after the signature change; what the change guarantees is that the signature itself adds no
-    device-to-host copy, and that the cache notices the failed capture once and keeps running the sweep eagerly with right results."""
+def test_tensor_indexed_getitem_sweep_is_captured(engines):
+    """A sweep with a gather by a resident index tensor and its scatter-add backward (definitions.py:186-189) under SweepCache on
+    the GPU. Eagerly mdhip_gather / mdhip_scatter read their bounds verdict back (NumPy raises IndexError at the call); inside a
+    capture they cannot — the kernels skip out-of-range positions, a scatter whose bounds pass found one writes nothing, and the
+    verdict waits in a pinned word for the next synchronisation (csrc/index.hip, md_sticky_check). So the sweep IS capturable, the
+    signature adds no device-to-host copy, and replays follow the index tensor's CURRENT contents."""
     from minidiff_amd.graph import SweepCache
     hip, _ = engines
     rng = np.random.default_rng(11)
@@ -279,10 +280,84 @@ def test_tensor_indexed_getitem_sweep_stays_eager_and_correct(engines):
         hip.sum(x[(idx, slice(None))] * 3.0).backward()
         return {"gx": x.grad}
 
-    exp = np.zeros_like(xh)
-    np.add.at(exp, ih, np.float32(3.0))
+    def expect(i):
+        e = np.zeros_like(xh)
+        np.add.at(e, i, np.float32(3.0))
+        return e
+
     with SweepCache(hip, validate_every=0) as cache:
         for _ in range(5):
             out = cache.run(step)
-            np.testing.assert_array_equal(out["gx"].as_numpy(), exp)
-        assert cache.stats["uncapturable"] == 1 and cache.stats["captured"] == 0 and cache.stats["eager"] == 5, cache.stats
+            np.testing.assert_array_equal(out["gx"].as_numpy(), expect(ih))
+        assert cache.stats["uncapturable"] == 0 and cache.stats["captured"] == 1 and cache.stats["replayed"] >= 2, cache.stats
+        # other indices in the SAME buffer: the replayed kernels read them
+        ih2 = rng.integers(-64, 64, 200)
+        idx._data[...] = nd.asarray(ih2)
+        out = cache.run(step)
+        np.testing.assert_array_equal(out["gx"].as_numpy(), expect(ih2))
+        # an index out of range at replay time: nothing faults, the error arrives with the next synchronisation — once
+        bad = ih2.copy(); bad[17] = 64
+        idx._data[...] = nd.asarray(bad)
+        out = cache.run(step)
+        with pytest.raises(IndexError, match="replayed graph"):
+            out["gx"].as_numpy()
+        idx._data[...] = nd.asarray(ih)
+        out = cache.run(step)
+        np.testing.assert_array_equal(out["gx"].as_numpy(), expect(ih))
+
+
+@pytest.mark.gpu
+def test_captured_gather_scatter_defer_their_bounds_verdict(lib, on_gpu):
+    """Library level: gathers / scatters of every flavour recorded into one graph (rows, elements, along-axis; SET and ADD, float and
+    integer), replayed with good and then with bad indices. A scatter that met a bad index leaves its destination untouched."""
+    assert on_gpu
+    import ctypes as C
+    from minidiff_amd import ndarray as nd
+    rng = np.random.default_rng(5)
+    table = rng.standard_normal((512, 64)).astype(np.float32)
+    rows = rng.integers(0, 512, 6000)                     # > 4096 rows: the sorted row path
+    few = rng.integers(0, 512, 40)                        # the serial path
+    cols = rng.integers(0, 64, (512, 3))
+    t, r, f, c = nd.asarray(table), nd.asarray(rows), nd.asarray(few), nd.asarray(cols)
+    acc, acc_i, small = nd.zeros((512, 64), np.float32), nd.zeros((512, 64), np.int64), nd.zeros((512, 64), np.float32)
+    upd = nd.asarray(np.ones((6000, 64), np.float32))
+    outs = {}
+
+    def body():
+        outs["g"] = t[r]                                  # gather rows
+        outs["e"] = t[f, 3]                               # gather elements
+        outs["a"] = nd.take_along_axis(t, c, 1)
+        nd.index_add(acc, r, upd)                         # float rows, duplicates: sort + apply
+        nd.index_add(acc_i, r, 1)                         # integer: atomics
+        small[f] = 2.0                                    # serial SET
+
+    nd._lib().sync()
+    h = C.c_void_p()
+    nd._lib().graph_begin()
+    try:
+        body()
+    finally:
+        nd._lib().graph_end(C.byref(h))
+    try:
+        nd._lib().graph_launch(h)
+        nd._lib().sync()
+        e_acc = np.zeros((512, 64), np.float32); np.add.at(e_acc, rows, 1.0)
+        assert np.array_equal(outs["g"].get(), table[rows]) and np.array_equal(outs["e"].get(), table[few, 3])
+        assert np.array_equal(outs["a"].get(), np.take_along_axis(table, cols, 1))
+        assert np.array_equal(acc.get(), e_acc) and np.array_equal(acc_i.get(), e_acc.astype(np.int64))
+        e_small = np.zeros((512, 64), np.float32); e_small[few] = 2.0
+        assert np.array_equal(small.get(), e_small)
+        # bad row index in the scatter-add's plan: the replay raises at the synchronisation and the scatters wrote nothing
+        rows_bad = rows.copy(); rows_bad[4321] = 512
+        r[...] = nd.asarray(rows_bad)
+        nd._lib().graph_launch(h)
+        with pytest.raises(IndexError, match="replayed graph"):
+            nd._lib().sync()
+        assert np.array_equal(acc.get(), e_acc) and np.array_equal(acc_i.get(), e_acc.astype(np.int64))
+        nd._lib().sync()                                  # reported once
+        r[...] = nd.asarray(rows)
+        nd._lib().graph_launch(h)
+        nd._lib().sync()
+        assert np.array_equal(acc.get(), 2 * e_acc)
+    finally:
+        nd._lib().graph_destroy(h)
