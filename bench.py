@@ -12,14 +12,16 @@ under "secondary" — value, ms per sweep and the roofline of their dominant
 kernels from HIP events — so that one driver run carries the HBM-bound numbers
 too (`--no-secondary` skips them).
 
-With N > 1 (one rank per GPU, launched by torch.distributed.run) the default
-workload is BASELINE's configs[3] (cfg4): the global batch of 8192 rows is split
-over the ranks (strong scaling), [W.grad || b.grad] is summed by RCCL all-reduce
-in row panels that leave while the weight-gradient GEMM is still running, and
-`tensors_per_s` = 8192 x sweeps/s, and `single_gpu_same_workload` holds the un-sharded cfg4 sweep timed on ONE GPU in the
-same job (the driver's N = 1 run is cfg2: another workload). `--workload cfg2` at N > 1 is the weak-scaling
-variant (every rank owns its own 4096-row block A_r; B.grad all-reduced); it is
-also run after the headline and reported under "secondary".
+With N > 1 (one rank per GPU) the headline stays the metric's own workload, cfg2, data-parallel
+the way north_star asks: every rank owns its own 4096 independent batch rows A_r (per-GPU work fixed:
+"scaling": "weak"), B is the replicated parameter, and B.grad is summed over the ranks by ONE RCCL
+all-reduce per sweep, sent in row panels that leave while the weight-gradient GEMM is still running.
+`value` = N x sweeps/s, so value(N) / (N x value(1)) is the scaling efficiency against the driver's N = 1
+run; `single_gpu_value` is the same sweep timed on ONE GPU in the same job (no collective), and
+`tensors_per_s` = 4096 x value (batch rows through forward+backward per second). After the headline the
+same job runs BASELINE's configs[3] (cfg4: ONE global batch of 8192 rows split over the ranks, strong
+scaling, bucket [W.grad || b.grad] all-reduced) and reports it as flat keys `cfg4_strong_*` together with
+its own single-GPU figure; `--workload cfg4` makes it the headline instead.
 
 `python bench.py --gpus N` with N > 1 and no rank environment starts its own N ranks
 (one child process per GPU, before anything in THIS process touches the GPU), forwards
@@ -551,6 +553,12 @@ def flat_keys(results):
             put(name + "_frac", roof.get("frac"))
             if roof.get("avg_launch_ms") is not None:
                 put(name + "_gemm_us", roof["avg_launch_ms"] * 1e3)
+            if name in ("cfg2_weak", "cfg4_strong"):    # N > 1 only: what the scaling of this config is judged by
+                put(name + "_ms_per_step", r.get("ms_per_step"))
+                put(name + "_tensors_per_s", r.get("tensors_per_s"))
+                put(name + "_single_gpu_passes_per_s", pick(r, "single_gpu_same_workload", "value"))
+                put(name + "_allreduce_alone_ms", pick(r, "config", "allreduce_alone_ms"))
+                put(name + "_allreduce_busbw_GBps", pick(r, "config", "allreduce_busbw_GBps"))
     return f
 
 
@@ -588,7 +596,7 @@ def main(entry=None):
     use_dist = world > 1 or force_dist
     WORLD, RANK, USE_DIST = world, rank, use_dist   # (run() shadows the lower-case names in its solo mode)
     if args.workload is None:
-        args.workload = "cfg4" if use_dist else "cfg2"
+        args.workload = "cfg2"      # at every N: the workload BASELINE's metric is quoted on (N > 1: weak scaling over batch rows)
     dist = torch = None
     if use_dist:
         import torch
@@ -881,8 +889,10 @@ def main(entry=None):
                        "allreduce_alone_ms": allreduce_ms, "allreduce_busbw_GBps": busbw},
             "roofline": roof, "kernels": detail,
         }
-        if workload == "cfg4":
-            res["tensors_per_s"] = (size or 8192) * value  # batch rows through forward+backward per second
+        if workload in ("cfg2", "cfg4"):
+            # batch rows through forward+backward per second (cfg4: one global batch; cfg2: every rank's own rows — `value`
+            # already counts all ranks' sweeps)
+            res["tensors_per_s"] = (size or DEFAULT_SIZE[workload]) * value
         if want_grads:   # the last sweep's gradients, copied to the host AFTER the timed region (the L-inf check against the oracle)
             res["_grads"] = {name: np.asarray(state[name].grad.as_numpy()) for name in GRAD_NAMES[workload]}
             if workload == "cfg4" and world == 1:
@@ -905,20 +915,22 @@ def main(entry=None):
     head = run(args.workload, args.lazy, args.steps, args.warmup, graph=args.graph, size=args.size, want_grads=check_grads)
     head_grads = head.pop("_grads", None)
     event_overhead_ms = timer.empty_bracket_ms()
-    # N > 1: the headline is the batch-sharded cfg4 sweep, the driver's N = 1 run is cfg2 — so the same job also times the
-    # UN-sharded sweep of the headline workload on one GPU (every rank on its own card, no collective; rank 0's figure)
-    solo = None
-    if world > 1 and not args.graph:
+    # N > 1: the same job also times the headline workload on ONE GPU (every rank on its own card, no collective; rank 0's
+    # figure) — the N = 1 value its scaling is judged against, from the same boxes and the same clocks
+    def solo_run(workload, lazy):
         gc.collect()
         lib.empty_cache()
-        r1 = run(args.workload, args.lazy, min(args.steps, 10), min(args.warmup, 2), size=args.size, solo=True)
-        solo = {"value": r1["value"], "unit": "passes/s", "ms_per_step": r1["ms_per_step"], "n_gpus": 1,
-                "workload": r1["config"]["workload"],
-                "note": "the headline workload un-sharded on ONE GPU, timed in this job (all ranks run it at once, no collective)"}
+        r1 = run(workload, lazy, min(args.steps, 10), min(args.warmup, 2), size=args.size, solo=True)
+        s = {"value": r1["value"], "unit": "passes/s", "ms_per_step": r1["ms_per_step"], "n_gpus": 1,
+             "workload": r1["config"]["workload"],
+             "note": "the workload un-sharded on ONE GPU, timed in this job (all ranks run it at once, no collective)"}
         if "tensors_per_s" in r1:
-            solo["tensors_per_s"] = r1["tensors_per_s"]
+            s["tensors_per_s"] = r1["tensors_per_s"]
         gc.collect()
         lib.empty_cache()
+        return s
+
+    solo = solo_run(args.workload, args.lazy) if world > 1 and not args.graph else None
 
     # ---- CPU leg (rank 0, N = 1): the NumPy engine on the same seeds, once per WORKLOAD — its passes/s (the reported baseline)
     # and its gradients, against which every device run of that workload (eager and lazy) is compared norm-wise
@@ -959,6 +971,9 @@ def main(entry=None):
                 lib.empty_cache()
             try:
                 r = run(wl, lz, k_sec, w_sec, size=args.size, keep=keep, want_grads=check_grads)
+                if use_dist:    # its own single-GPU figure, same job
+                    keep.clear()
+                    r["single_gpu_same_workload"] = solo_run(wl, lz)
                 grads = r.pop("_grads", None)
                 if check_grads:
                     cpu_leg(name, wl, grads)

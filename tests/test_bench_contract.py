@@ -88,20 +88,28 @@ def test_bench_flat_per_config_keys(lib, on_gpu, tmp_path):
 
 
 def _check_two_rank_line(d, full):
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "dp2"
-    assert d["config"]["workload"].startswith("cfg4") and d["tensors_per_s"] == pytest.approx(64 * d["value"], rel=1e-3)
-    assert d["config"]["allreduce_panels"] == 2 and d["config"]["allreduce_bytes"] == (512 * 512 + 512) * 4
+    # the headline at N > 1 is the metric's own workload (cfg2), weak scaling over batch rows: value = N x sweeps/s
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["workload"].startswith("cfg2") and d["tensors_per_s"] == pytest.approx(64 * d["value"], rel=1e-3)
+    assert d["value"] == pytest.approx(2 * 1e3 / d["ms_per_step"], rel=1e-3)
+    assert d["config"]["allreduce_bytes"] == 64 * 64 * 4 and d["config"]["allreduce_panels"] >= 1
     assert d["config"]["collective"] == "gloo-host(test)" and d["config"]["rccl_ranks"] is None
     head = full["head"]
-    # every sweep (pre-roll + warm-up + timed + the per-kernel detail pass) sent its collectives from inside backward()
-    assert head["config"]["allreduce_overlapped_sweeps"] == head["preroll_sweeps"] + 1 + 2 + 10 + 2   # (+ ten single synchronised sweeps)
-    sec = full["secondary"]["cfg2_weak"]
-    assert "error" not in sec and sec["scaling"] == "weak" and sec["config"]["collective"] == "gloo-host(test)" and sec["value"] > 0
-    assert d["roofline"]["cfg2_weak_passes_per_s"] == pytest.approx(sec["value"], rel=1e-3)
-    # the same job's N = 1 figure of the headline workload (un-sharded batch, no collective)
+    # every sweep (pre-roll + warm-up + timed + ten single synchronised sweeps) sent its collective from inside backward()
+    assert head["config"]["allreduce_overlapped_sweeps"] == head["preroll_sweeps"] + 1 + 2 + 10
+    # the same job's N = 1 figure of the headline workload (no collective)
     solo = full["single_gpu_same_workload"]
-    assert solo["n_gpus"] == 1 and solo["value"] > 0 and solo["workload"].startswith("cfg4") and solo["tensors_per_s"] == pytest.approx(64 * solo["value"])
+    assert solo["n_gpus"] == 1 and solo["value"] > 0 and solo["workload"].startswith("cfg2") and solo["tensors_per_s"] == pytest.approx(64 * solo["value"])
     assert d["single_gpu_value"] == pytest.approx(solo["value"], rel=1e-3)
+    # then BASELINE's configs[3]: ONE global batch split over the ranks (strong), its bucket all-reduced in row panels
+    sec = full["secondary"]["cfg4_strong"]
+    assert "error" not in sec and sec["scaling"] == "strong" and sec["config"]["collective"] == "gloo-host(test)" and sec["value"] > 0
+    assert sec["config"]["allreduce_panels"] == 2 and sec["config"]["allreduce_bytes"] == (512 * 512 + 512) * 4
+    assert sec["tensors_per_s"] == pytest.approx(64 * sec["value"], rel=1e-3)
+    r = d["roofline"]
+    assert r["cfg4_strong_passes_per_s"] == pytest.approx(sec["value"], rel=1e-3)
+    assert r["cfg4_strong_single_gpu_passes_per_s"] == pytest.approx(sec["single_gpu_same_workload"]["value"], rel=1e-3)
+    assert r["cfg4_strong_tensors_per_s"] == pytest.approx(sec["tensors_per_s"], rel=1e-3) and r["cfg4_strong_ms_per_step"] > 0
 
 
 TWO_RANK_ENV = dict(MDHIP_BENCH_HOST_COMM="1", MDHIP_BENCH_CFG4_DIM="512", MDHIP_DP_PANELS="2", OMP_NUM_THREADS="2")
@@ -110,8 +118,8 @@ TWO_RANK_ARGS = ["--gpus", "2", "--size", "64", "--steps", "2", "--warmup", "1",
 
 def test_bench_two_ranks_control_flow_over_gloo(lib, on_gpu, tmp_path):
     """bench.py's N > 1 branch started the way torch.distributed.run starts it (rank environment given): two real processes
-    (gloo control plane, HostComm on the CPU double's memory): cfg4 is the default workload, strong scaling, tensors_per_s, the
-    weight gradient all-reduced in row panels, then the weak-scaling cfg2 with a second communicator. Numbers mean nothing;
+    (gloo control plane, HostComm on the CPU double's memory): cfg2 — the metric's workload — is the headline at every N (weak scaling
+    over batch rows, B.grad all-reduced), then the strong-scaling cfg4 with a second communicator and its own single-GPU figure. Numbers mean nothing;
     the flow and the line's shape do."""
     if on_gpu:
         pytest.skip("CPU-double check")
