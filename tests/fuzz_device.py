@@ -365,7 +365,14 @@ def one_case(rng, big):
                 assert got.shape == exp.shape and got.dtype == exp.dtype
                 # (float16: NumPy rounds every step of its five to half; the device computes them in float32 and rounds once)
                 tol = 2e-5 if h.dtype == np.float32 else 4e-3 if h.dtype == np.float16 else 1e-11
-                assert np.abs(got.astype(np.float64) - exp.astype(np.float64)).max() <= tol * (float(np.abs(hh).max()) + 1.0), f"std {h.shape} ax={ax}"
+                g64, e64 = got.astype(np.float64), exp.astype(np.float64)
+                if h.dtype == np.float16:
+                    # (.. so NumPy's half sum of squares overflows to inf from |x| ~ 30 on a 64-element axis where the device's
+                    # float32 sum does not: compared where NumPy stayed finite)
+                    fin = np.isfinite(e64)
+                    g64, e64 = g64[fin], e64[fin]
+                if e64.size:
+                    assert np.abs(g64 - e64).max() <= tol * (float(np.abs(hh).max()) + 1.0), f"std {h.shape} ax={ax}"
         elif kind == "astype":
             to = DTYPES[int(rng.integers(0, len(DTYPES)))]
             if h.dtype.kind == "f" and np.dtype(to).kind in "iu":
