@@ -745,10 +745,14 @@ def main(entry=None):
             sweep()
         lib.sync()
         captured = None
-        # N > 1: the sweep's kernels are short (65-250 us at 8 ranks) and ~7 us of Python dispatch per backend call would sit
-        # between them: replay the sweep as hipGraph SEGMENTS with the collectives between them (graph.SegmentedSweep;
-        # MDHIP_DP_GRAPH=0 keeps the eager sweep). A build that cannot capture (the CPU double) stays eager.
-        segmented = bool(use_dist and comm is not None and sync.active and not graph and os.environ.get("MDHIP_DP_GRAPH", "1") != "0")
+        # N > 1: where the sweep's kernels are short (cfg4 at 8 ranks: 65-250 us) ~7 us of Python dispatch per backend call would
+        # sit between them: the sweep can be replayed as hipGraph SEGMENTS with the collectives between them (graph.SegmentedSweep).
+        # Where they are long (cfg2: 0.24-0.9 ms) the host runs ahead anyway and every segment cut costs ~14 us of graph start-up.
+        # MDHIP_DP_GRAPH: "0" eager sweeps, "1" segments, unset = a three-sweep trial of both before the timed region, the faster
+        # one (max over ranks, so every rank takes the same) runs the K timed sweeps. A build that cannot capture stays eager.
+        dp_graph = os.environ.get("MDHIP_DP_GRAPH", "auto")
+        trial = None
+        segmented = bool(use_dist and comm is not None and sync.active and not graph and dp_graph != "0")
         if segmented:
             from minidiff_amd.graph import can_capture
             segmented = can_capture(lib)
@@ -764,6 +768,35 @@ def main(entry=None):
                 captured = SegmentedSweep(sweep, comm)
                 captured.replay()
                 run_one = captured.replay
+                if dp_graph != "1":
+                    def trial_ms(fn, n=3):
+                        fn()
+                        lib.sync()
+                        barrier()
+                        t = time.perf_counter()
+                        for _ in range(n):
+                            fn()
+                        lib.sync()
+                        dt = (time.perf_counter() - t) / n * 1e3
+                        if dist is not None and dist.is_initialized():
+                            tt = torch.tensor([dt], dtype=torch.float64)
+                            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                            dt = float(tt.item())
+                        return dt
+                    trial = {"segments_ms": trial_ms(captured.replay)}
+                    # (the eager candidate as it would run in the timed region: its GEMM launches carry the roofline's events)
+                    warm_events, timer.used = timer.used, []
+                    timer.only, timer.enabled = {"matmul"}, True
+                    trial["eager_ms"] = trial_ms(sweep)
+                    timer.only, timer.enabled = None, False
+                    timer.collect()        # (the trial's own brackets: recycled, not priced)
+                    timer.used = warm_events
+                    if trial["eager_ms"] <= trial["segments_ms"]:
+                        timer.collect()    # (.. nor the warm-up's: the timed region's own launches price the roofline)
+                        segs = {"segments": captured.segments, "collective_calls": captured.calls}
+                        captured.close()
+                        captured, segmented, run_one = None, False, sweep
+                        trial.update(segs)
             except RuntimeError as e:
                 captured, segmented = None, False
                 try:        # the failed capture may have stopped inside backward(): put the gradient sync back to "between sweeps"
@@ -884,6 +917,7 @@ def main(entry=None):
             "single_sweep_ms": {"median": single[len(single) // 2], "min": single[0], "n": len(single)} if single else None,
             "config": {"workload": describe(workload, n, lazy), "parallelism": f"dp{world}", "lazy_fusion": bool(lazy),
                        "graph_replay": bool(graph) or ({"segments": captured.segments, "collective_calls": captured.calls} if segmented else False),
+                       "sweep_trial_eager_ms": trial["eager_ms"] if trial else None, "sweep_trial_segments_ms": trial["segments_ms"] if trial else None,
                        "collective": comm_kind, "rccl_ranks": n_rccl, "allreduce_bytes": sync.nbytes if use_dist else 0,
                        "allreduce_overlapped_sweeps": sync.overlapped, "allreduce_panels": getattr(sync, "panels", 1),
                        "allreduce_alone_ms": allreduce_ms, "allreduce_busbw_GBps": busbw},
@@ -1017,7 +1051,7 @@ def main(entry=None):
             for wl, c in cpu_all.items():      # the NumPy engine on every config (cfg3: N = 1e7 sample, scaled linearly)
                 if wl != args.workload:
                     cpu[f"{wl}_value"] = c["value"]
-        cfg = {k: v for k, v in head["config"].items() if not isinstance(v, (dict, list))}
+        cfg = {k: v for k, v in head["config"].items() if not isinstance(v, (dict, list)) and not (k.startswith("sweep_trial_") and v is None)}
         if not use_dist:   # (one GPU: no collective — the all-reduce fields would only say so)
             cfg = {k: v for k, v in cfg.items() if not k.startswith("allreduce_") and k != "rccl_ranks"}
         if isinstance(head["config"].get("graph_replay"), dict):

@@ -154,7 +154,8 @@ def test_bench_distributed_path_on_one_gpu(on_gpu, comm, workload):
     import json
     root = os.path.dirname(HERE)
     env = dict(os.environ, MDHIP_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MDHIP_DP_GRAPH="1")    # (segments forced: by default a three-sweep trial picks between them and eager sweeps)
     import tempfile
     detail = os.path.join(tempfile.mkdtemp(prefix="mdhip_bench_"), "detail.json")
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
@@ -175,3 +176,22 @@ def test_bench_distributed_path_on_one_gpu(on_gpu, comm, workload):
     # (cfg4 over RCCL: the weight-gradient panels + the join; the torch communicator has one synchronous all-reduce and no join)
     assert isinstance(seg, dict) and seg["segments"] >= 2 and seg["collective_calls"] >= (2 if comm == "rccl" else 1), seg
     assert head["config"]["allreduce_overlapped_sweeps"] == head["preroll_sweeps"] + 1 + 1 + 1 + 10 + (3 if workload == "cfg4" else 0)
+
+
+@pytest.mark.gpu
+def test_bench_distributed_path_picks_its_sweep_mode(on_gpu):
+    """Without MDHIP_DP_GRAPH the N > 1 branch times three eager sweeps against three segmented replays before the timed region and
+    runs the faster; the line says which (`graph_replay`) and carries both trial times."""
+    assert on_gpu
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MDHIP_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MDHIP_DP_GRAPH", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--size", "1024", "--no-cpu-baseline", "--no-secondary"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    cfg = json.loads(p.stdout.strip().splitlines()[-1])["config"]
+    assert cfg["workload"].startswith("cfg2") and cfg["collective"] == "rccl-direct"
+    assert cfg["sweep_trial_eager_ms"] > 0 and cfg["sweep_trial_segments_ms"] > 0
+    assert cfg["graph_replay"] is (cfg["sweep_trial_segments_ms"] < cfg["sweep_trial_eager_ms"])
