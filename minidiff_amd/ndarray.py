@@ -590,37 +590,37 @@ class DeviceArray(_fp.ArrayBase if _fp is not None else object):
         return squeeze(self, axis)
 
     def sum(self, axis=None, dtype=None, out=None, keepdims=False):
-        return sum(self, axis=axis, dtype=dtype, keepdims=keepdims)
+        return sum(self, axis=axis, dtype=dtype, out=out, keepdims=keepdims)
 
     def mean(self, axis=None, dtype=None, out=None, keepdims=False):
-        return mean(self, axis=axis, dtype=dtype, keepdims=keepdims)
+        return mean(self, axis=axis, dtype=dtype, out=out, keepdims=keepdims)
 
     def max(self, axis=None, out=None, keepdims=False):
-        return max(self, axis=axis, keepdims=keepdims)
+        return max(self, axis=axis, out=out, keepdims=keepdims)
 
     def min(self, axis=None, out=None, keepdims=False):
-        return min(self, axis=axis, keepdims=keepdims)
+        return min(self, axis=axis, out=out, keepdims=keepdims)
 
     def prod(self, axis=None, dtype=None, out=None, keepdims=False):
-        return prod(self, axis=axis, dtype=dtype, keepdims=keepdims)
+        return prod(self, axis=axis, dtype=dtype, out=out, keepdims=keepdims)
 
     def any(self, axis=None, out=None, keepdims=False):
-        return any(self, axis=axis, keepdims=keepdims)
+        return any(self, axis=axis, out=out, keepdims=keepdims)
 
     def all(self, axis=None, out=None, keepdims=False):
-        return all(self, axis=axis, keepdims=keepdims)
+        return all(self, axis=axis, out=out, keepdims=keepdims)
 
     def argmax(self, axis=None, out=None, keepdims=False):
-        return argmax(self, axis=axis, keepdims=keepdims)
+        return argmax(self, axis=axis, out=out, keepdims=keepdims)
     def clip(self, a_min=None, a_max=None, **kw): return clip(self, a_min, a_max, **kw)
-    def std(self, axis=None, dtype=None, out=None, ddof=0, keepdims=False): return std(self, axis=axis, dtype=dtype, ddof=ddof, keepdims=keepdims)
+    def std(self, axis=None, dtype=None, out=None, ddof=0, keepdims=False): return std(self, axis=axis, dtype=dtype, out=out, ddof=ddof, keepdims=keepdims)
     def swapaxes(self, a0, a1): return swapaxes(self, a0, a1)
     def nonzero(self): return nonzero(self)
     def repeat(self, repeats, axis=None): return repeat(self, repeats, axis=axis)
 
 
     def argmin(self, axis=None, out=None, keepdims=False):
-        return argmin(self, axis=axis, keepdims=keepdims)
+        return argmin(self, axis=axis, out=out, keepdims=keepdims)
 
     def dot(self, other):
         return dot(self, other)
@@ -745,7 +745,8 @@ def _to_host_nested(seq):
     return out
 
 
-def array(obj, dtype=None, copy=True, **_) -> DeviceArray:
+def array(obj, dtype=None, copy=True, **kw) -> DeviceArray:
+    _defaults_only("array", kw)
     """tensor_constructor (reference: numpy.py:15 ``np.array``)."""
     if isinstance(obj, DeviceArray):
         if dtype is not None and np.dtype(dtype) != obj.dtype:
@@ -923,12 +924,17 @@ def _binary(ufunc, code, a, b, out=None):
         shape = a.shape if a_arr else b.shape
     if code == _capi.B_POW and cdt.kind == "i" and _prod(shape) > 0:
         _check_int_power(b)      # (NumPy raises from inside its loop: an EMPTY result never meets the negative exponent)
-    if _capi.B_EQ <= code <= _capi.B_GE and cdt.kind in "iu" and out is None:
+    if _capi.B_EQ <= code <= _capi.B_GE and cdt.kind in "iu":
         # a Python int beyond the loop dtype's range compares as the number it is (NumPy 2: `u64_array >= -1` is all True,
         # `i32_array == 2**40` all False) — the answer does not depend on the array's values
         const = _oob_compare(code, a, b, cdt)
         if const is not None:
-            return full(shape, const, dtype=np.bool_)
+            if out is None:
+                return full(shape, const, dtype=np.bool_)
+            if shape != out.shape:
+                raise ValueError(f"non-broadcastable output operand with shape {out.shape} doesn't match the broadcast shape {shape}")
+            _copy_into(out, const)      # (bool casts safely into every dtype)
+            return out
     if _LAZY and out is None and not ((a_arr and a._code >= _NARROW_MIN) or (b_arr and b._code >= _NARROW_MIN)):
         # (storage-only operands are never leaves of a fused program: the interpreter and the generated kernels read the five compute dtypes)
         pcdt = _FLOAT_DT.get(cdt)
@@ -1112,16 +1118,73 @@ def _fill(dst: DeviceArray, value):
 # =============================================================================
 # elementwise API (names follow numpy / the backend table)
 # =============================================================================
+_DEFAULT_KW = {"where": (True,), "subok": (True,), "order": ("K", "C", "A"), "casting": ("same_kind",), "copy": (True,), "initial": (), "like": (),
+               "device": (), "signature": (), "mean": (), "correction": (), "out": (), "dtype": (), "ndmin": (0,)}
+
+
+def _defaults_only(name, kw):
+    """Keywords of the NumPy signature this backend has no code for: accepted at their defaults (None, or the values above), refused
+    otherwise — a keyword silently dropped would answer a different question than the one asked."""
+    for k, v in kw.items():
+        if k not in _DEFAULT_KW:
+            raise TypeError(f"{name}() got an unexpected keyword argument '{k}'")
+        if v is not None and v is not np._NoValue and not builtins_any(v is d or (type(v) is type(d) and v == d) for d in _DEFAULT_KW[k]):
+            raise TypeError(f"{name}(): the keyword {k} is not supported by the MI355X backend at this value ({type(v).__name__})")
+
+
+def _finish_out(res, out, name):
+    """`out=` of a reduction: NumPy's shape rule and same-kind cast, then the result lands in the caller's array."""
+    if out is None:
+        return res
+    if not isinstance(out, DeviceArray):
+        raise TypeError("output must be an array")
+    if out.shape != res.shape:
+        raise ValueError(f"output parameter for reduction operation {name} has the wrong shape: {out.shape} instead of {res.shape}")
+    if not np.can_cast(res.dtype, out.dtype, casting="same_kind"):
+        raise TypeError(f"Cannot cast ufunc '{name}' output from {res.dtype!r} to {out.dtype!r} with casting rule 'same_kind'")
+    _copy_into(out, res)
+    return out
+
+
+def _ufunc_kwargs(name, out, kw):
+    """NumPy's ufunc keywords: `out` (an array or a 1-tuple) is honoured; the others are accepted at their defaults and refused
+    otherwise — a keyword silently dropped would answer a different question than the one asked."""
+    for k, v in kw.items():
+        if k not in ("where", "dtype", "casting", "order", "subok", "signature"):
+            raise TypeError(f"{name}() got an unexpected keyword argument '{k}'")
+        if not (v is None or (k in ("where", "subok") and v is True) or (k == "casting" and isinstance(v, str) and v == "same_kind") or
+                (k == "order" and isinstance(v, str) and v == "K")):
+            raise TypeError(f"{name}(): the keyword {k} is not supported by the MI355X backend at this value ({type(v).__name__})")
+    if isinstance(out, tuple):
+        if len(out) != 1:
+            raise ValueError("The 'out' tuple must have exactly one entry per ufunc output")
+        out = out[0]
+    if out is not None and not isinstance(out, DeviceArray):
+        raise TypeError("return arrays must be of ArrayType")
+    return out
+
+
 def _mk_unary(ufunc, code):
-    def f(x, **kw):
-        return _unary(ufunc, code, x)
+    def f(x, out=None, **kw):
+        out = _ufunc_kwargs(ufunc.__name__, out, kw)
+        res = _unary(ufunc, code, x)
+        if out is None:
+            return res
+        if res.shape != out.shape:
+            raise ValueError(f"non-broadcastable output operand with shape {out.shape} doesn't match the broadcast shape {res.shape}")
+        if not np.can_cast(res.dtype, out.dtype, casting="same_kind"):
+            raise np._core._exceptions._UFuncOutputCastingError(ufunc, "same_kind", res.dtype, out.dtype, 0)
+        _copy_into(out, res)
+        return out
     f.__name__ = ufunc.__name__
     return f
 
 
 def _mk_binary(ufunc, code):
-    def f(a, b, **kw):
-        return _binary(ufunc, code, a, b)
+    def f(a, b, out=None, **kw):
+        if out is not None or kw:
+            out = _ufunc_kwargs(ufunc.__name__, out, kw)
+        return _binary(ufunc, code, a, b, out=out)
     f.__name__ = ufunc.__name__
     return f
 
@@ -1206,6 +1269,8 @@ def clip(a, a_min=None, a_max=None, **kw):
         a_min = kw.pop("min")
     if "max" in kw:
         a_max = kw.pop("max")
+    out = kw.pop("out", None)
+    _defaults_only("clip", kw)
     res = a if isinstance(a, DeviceArray) else asarray(a)
     touched = False
     if a_min is not None:
@@ -1214,10 +1279,15 @@ def clip(a, a_min=None, a_max=None, **kw):
     if a_max is not None:
         res = minimum(res, a_max)
         touched = True
+    if out is not None:
+        return _finish_out(res, out, "clip")
     return res if touched else copy(res)
 
 
-def astype(a, dtype, copy=True, **_):
+def astype(a, dtype, copy=True, **kw):
+    if kw.get("casting") == "unsafe":      # (astype's own default)
+        kw = {k: v for k, v in kw.items() if k != "casting"}
+    _defaults_only("astype", kw)
     a = asarray(a)
     dtype = np.dtype(dtype)
     if dtype == a.dtype and not copy:
@@ -1237,7 +1307,8 @@ def _convert(a: "DeviceArray", dtype) -> "DeviceArray":
     return res
 
 
-def copy(a, order="K", **_):
+def copy(a, order="K", **kw):
+    _defaults_only("copy", kw)
     a = asarray(a)
     res = DeviceArray.empty(a.shape, a.dtype)
     if a._code >= _NARROW_MIN:
@@ -1324,7 +1395,8 @@ def _reshape_view_strides(shape, strides, newshape):
     return new_strides
 
 
-def reshape(a, shape=None, order="C", newshape=None, **_):
+def reshape(a, shape=None, order="C", newshape=None, **kw):
+    _defaults_only("reshape", kw)
     a = asarray(a)
     if shape is None:
         shape = newshape
@@ -1371,7 +1443,8 @@ def flatten(a, order="C"):
     return copy(r) if r._buf is a._buf else r
 
 
-def broadcast_to(a, shape, **_):
+def broadcast_to(a, shape, **kw):
+    _defaults_only("broadcast_to", kw)
     a = asarray(a)
     shape = _normalize_shape(shape)
     if len(shape) < a.ndim:
@@ -1693,32 +1766,38 @@ def _sum_dtype(a_dtype, dtype):
     return a_dtype
 
 
-def sum(a, axis=None, dtype=None, out=None, keepdims=False, **_):
+def sum(a, axis=None, dtype=None, out=None, keepdims=False, **kw):
+    _defaults_only("sum", kw)
     a = asarray(a)
-    return _reduce(_capi.R_SUM, a, axis, keepdims, _sum_dtype(a.dtype, dtype))
+    return _finish_out(_reduce(_capi.R_SUM, a, axis, keepdims, _sum_dtype(a.dtype, dtype)), out, "add")
 
 
-def prod(a, axis=None, dtype=None, out=None, keepdims=False, **_):
+def prod(a, axis=None, dtype=None, out=None, keepdims=False, **kw):
+    _defaults_only("prod", kw)
     a = asarray(a)
-    return _reduce(_capi.R_PROD, a, axis, keepdims, _sum_dtype(a.dtype, dtype))
+    return _finish_out(_reduce(_capi.R_PROD, a, axis, keepdims, _sum_dtype(a.dtype, dtype)), out, "multiply")
 
 
-def max(a, axis=None, out=None, keepdims=False, **_):
+def max(a, axis=None, out=None, keepdims=False, **kw):
+    _defaults_only("max", kw)
     a = asarray(a)
-    return _reduce(_capi.R_MAX, a, axis, keepdims, a.dtype)
+    return _finish_out(_reduce(_capi.R_MAX, a, axis, keepdims, a.dtype), out, "maximum")
 
 
-def min(a, axis=None, out=None, keepdims=False, **_):
+def min(a, axis=None, out=None, keepdims=False, **kw):
+    _defaults_only("min", kw)
     a = asarray(a)
-    return _reduce(_capi.R_MIN, a, axis, keepdims, a.dtype)
+    return _finish_out(_reduce(_capi.R_MIN, a, axis, keepdims, a.dtype), out, "minimum")
 
 
-def any(a, axis=None, out=None, keepdims=False, **_):
-    return _reduce(_capi.R_ANY, a, axis, keepdims, np.dtype(np.bool_))
+def any(a, axis=None, out=None, keepdims=False, **kw):
+    _defaults_only("any", kw)
+    return _finish_out(_reduce(_capi.R_ANY, a, axis, keepdims, np.dtype(np.bool_)), out, "logical_or")
 
 
-def all(a, axis=None, out=None, keepdims=False, **_):
-    return _reduce(_capi.R_ALL, a, axis, keepdims, np.dtype(np.bool_))
+def all(a, axis=None, out=None, keepdims=False, **kw):
+    _defaults_only("all", kw)
+    return _finish_out(_reduce(_capi.R_ALL, a, axis, keepdims, np.dtype(np.bool_)), out, "logical_and")
 
 
 def _arg_reduce(code, a, axis, keepdims):
@@ -1734,12 +1813,14 @@ def _arg_reduce(code, a, axis, keepdims):
     return _reduce(code, a, int(axis), keepdims, np.dtype(np.int64))
 
 
-def argmax(a, axis=None, out=None, keepdims=False, **_):
-    return _arg_reduce(_capi.R_ARGMAX, a, axis, keepdims)
+def argmax(a, axis=None, out=None, keepdims=False, **kw):
+    _defaults_only("argmax", kw)
+    return _finish_out(_arg_reduce(_capi.R_ARGMAX, a, axis, keepdims), out, "argmax")
 
 
-def argmin(a, axis=None, out=None, keepdims=False, **_):
-    return _arg_reduce(_capi.R_ARGMIN, a, axis, keepdims)
+def argmin(a, axis=None, out=None, keepdims=False, **kw):
+    _defaults_only("argmin", kw)
+    return _finish_out(_arg_reduce(_capi.R_ARGMIN, a, axis, keepdims), out, "argmin")
 
 
 def _count(a, axis):
@@ -1750,14 +1831,15 @@ def _count(a, axis):
     return n
 
 
-def mean(a, axis=None, dtype=None, out=None, keepdims=False, **_):
+def mean(a, axis=None, dtype=None, out=None, keepdims=False, **kw):
+    _defaults_only("mean", kw)
     # numpy/_core/_methods.py:_mean — sum in the float dtype, then true_divide by the count
     a = asarray(a)
     n = _count(a, axis)
     if dtype is None and a.dtype.kind in "bi":
         dtype = np.dtype(np.float64)
     s = sum(a, axis=axis, dtype=dtype, keepdims=keepdims)
-    return _binary(np.true_divide, _capi.B_TRUE_DIV, s, n, out=s)
+    return _finish_out(_binary(np.true_divide, _capi.B_TRUE_DIV, s, n, out=s), out, "mean")
 
 
 def _std_fused(a, axis, dtype, ddof, keepdims, n):
@@ -1792,7 +1874,8 @@ def _std_fused(a, axis, dtype, ddof, keepdims, n):
     return res if keepdims else reshape(res, a.shape[:ax] + a.shape[ax + 1:])
 
 
-def std(a, axis=None, dtype=None, out=None, ddof=0, keepdims=False, **_):
+def std(a, axis=None, dtype=None, out=None, ddof=0, keepdims=False, **kw):
+    _defaults_only("std", kw)
     # numpy/_core/_methods.py:_var/_std — mean, centred squares, mean, sqrt
     a = asarray(a)
     n = _count(a, axis)
@@ -1800,7 +1883,7 @@ def std(a, axis=None, dtype=None, out=None, ddof=0, keepdims=False, **_):
         dtype = np.dtype(np.float64)
     fused = _std_fused(a, axis, dtype, ddof, keepdims, n)
     if fused is not None:
-        return fused
+        return _finish_out(fused, out, "std")
     arrmean = sum(a, axis=axis, dtype=dtype, keepdims=True)
     arrmean = _binary(np.true_divide, _capi.B_TRUE_DIV, arrmean, n, out=arrmean)
     x = subtract(a, arrmean)
@@ -1808,7 +1891,7 @@ def std(a, axis=None, dtype=None, out=None, ddof=0, keepdims=False, **_):
     ret = sum(x, axis=axis, dtype=dtype, keepdims=keepdims)
     rcount = builtins_max(n - ddof, 0)
     ret = _binary(np.true_divide, _capi.B_TRUE_DIV, ret, rcount, out=ret)
-    return sqrt(ret)
+    return _finish_out(sqrt(ret), out, "std")
 
 
 # =============================================================================
@@ -1833,7 +1916,8 @@ def _as3d(x: DeviceArray, batch_shape: tuple):
     return full._view(full._offset, (B, r, c), (st[0], full._strides[-2], full._strides[-1]))
 
 
-def matmul(a, b, out=None, **_):
+def matmul(a, b, out=None, **kw):
+    _defaults_only("matmul", kw)
     """np.matmul (numpy.py:84). `out`: like NumPy's — a C-contiguous array of the result's shape and dtype that
     receives the product (dp.GradSync points it at a row panel of the all-reduce bucket)."""
     a, b = asarray(a), asarray(b)
@@ -1907,7 +1991,8 @@ def _unalias_out(out, *operands):
     return out
 
 
-def dot(a, b, **_):
+def dot(a, b, **kw):
+    _defaults_only("dot", kw)
     a_s = not isinstance(a, DeviceArray) and np.ndim(a) == 0
     b_s = not isinstance(b, DeviceArray) and np.ndim(b) == 0
     if a_s or b_s:
@@ -1970,19 +2055,22 @@ def tensordot(a, b, axes=2):
 _DEFAULT_FLOAT = np.dtype(np.float64)
 
 
-def zeros(shape, dtype=None, **_):
+def zeros(shape, dtype=None, **kw):
+    _defaults_only("zeros", kw)
     res = DeviceArray.empty(shape, dtype or _DEFAULT_FLOAT)
     _fill(res, 0)
     return res
 
 
-def ones(shape, dtype=None, **_):
+def ones(shape, dtype=None, **kw):
+    _defaults_only("ones", kw)
     res = DeviceArray.empty(shape, dtype or _DEFAULT_FLOAT)
     _fill(res, 1)
     return res
 
 
-def full(shape, fill_value, dtype=None, **_):
+def full(shape, fill_value, dtype=None, **kw):
+    _defaults_only("full", kw)
     if dtype is None:
         dtype = fill_value.dtype if isinstance(fill_value, (DeviceArray, np.generic)) else np.array(fill_value).dtype
     res = DeviceArray.empty(shape, dtype)
@@ -1998,19 +2086,23 @@ def _like_dtype(a, dtype):
     return np.asarray(a).dtype
 
 
-def zeros_like(a, dtype=None, **_):
+def zeros_like(a, dtype=None, **kw):
+    _defaults_only("zeros_like", kw)
     return zeros(np.shape(a) if not isinstance(a, DeviceArray) else a.shape, _like_dtype(a, dtype))
 
 
-def ones_like(a, dtype=None, **_):
+def ones_like(a, dtype=None, **kw):
+    _defaults_only("ones_like", kw)
     return ones(np.shape(a) if not isinstance(a, DeviceArray) else a.shape, _like_dtype(a, dtype))
 
 
-def full_like(a, fill_value, dtype=None, **_):
+def full_like(a, fill_value, dtype=None, **kw):
+    _defaults_only("full_like", kw)
     return full(np.shape(a) if not isinstance(a, DeviceArray) else a.shape, fill_value, _like_dtype(a, dtype))
 
 
-def arange(*args, dtype=None, **_):
+def arange(*args, dtype=None, **kw):
+    _defaults_only("arange", kw)
     args = [x.item() if isinstance(x, (DeviceArray, np.generic)) else x for x in args]
     if len(args) == 1:
         start, stop, step = 0, args[0], 1
@@ -2036,7 +2128,8 @@ def arange(*args, dtype=None, **_):
     return res
 
 
-def concatenate(arrays, axis=0, **_):
+def concatenate(arrays, axis=0, **kw):
+    _defaults_only("concatenate", kw)
     arrays = [asarray(x) for x in arrays]
     if not arrays:
         raise ValueError("need at least one array to concatenate")
@@ -2071,7 +2164,8 @@ def concatenate(arrays, axis=0, **_):
     return res
 
 
-def stack(arrays, axis=0, **_):
+def stack(arrays, axis=0, **kw):
+    _defaults_only("stack", kw)
     arrays = [asarray(x) for x in arrays]
     if not arrays:
         raise ValueError("need at least one array to stack")

@@ -125,3 +125,51 @@ def test_integer_power_with_negative_exponents(lib):
         exp = np.power(empty.get(), e.get() if isinstance(e, nd.DeviceArray) else e)
         assert got.shape == exp.shape and got.dtype == exp.dtype
     np.testing.assert_array_equal(nd.power(base, nd.asarray(np.array([0, 2, 3], dtype=np.int32))).get(), np.power(base.get(), np.array([0, 2, 3], dtype=np.int32)))
+
+
+def test_keywords_are_honoured_or_refused_never_dropped(lib):
+    """NumPy keywords of the table's functions: `out=` lands the result in the caller's array (ufuncs, reductions, mean / std) under
+    NumPy's shape and same-kind rules; a keyword this backend has no code for is accepted at its default and raises TypeError at any
+    other value — never silently ignored."""
+    from minidiff_amd import ndarray as nd
+    rng = np.random.default_rng(3)
+    a, b = rng.standard_normal((4, 5)).astype(np.float32), rng.standard_normal((4, 5)).astype(np.float32)
+    da, db = nd.asarray(a), nd.asarray(b)
+    for name in ("add", "multiply", "less", "maximum"):
+        o64, r64 = nd.zeros((4, 5), np.float64), np.zeros((4, 5), np.float64)
+        ret = getattr(nd, name)(da, db, out=o64)
+        getattr(np, name)(a, b, out=r64)
+        assert ret is o64 and np.array_equal(o64.get(), r64), name
+        ret = getattr(nd, name)(da, db, out=(o64,), where=True, casting="same_kind", dtype=None)
+        assert ret is o64
+    o, r = nd.zeros((4, 5), np.float32), np.zeros((4, 5), np.float32)
+    assert nd.sin(da, out=o) is o
+    np.sin(a, out=r)
+    assert np.allclose(o.get(), r, rtol=1e-6)
+    with pytest.raises(np._core._exceptions._UFuncOutputCastingError):
+        nd.add(da, db, out=nd.zeros((4, 5), np.int32))
+    with pytest.raises(ValueError, match="non-broadcastable"):
+        nd.add(da, db, out=nd.zeros((5, 4), np.float32))
+    with pytest.raises(ValueError, match="non-broadcastable"):
+        nd.sin(da, out=nd.zeros((5, 4), np.float32))
+    for name in ("sum", "prod", "max", "min", "mean", "std", "argmax", "any"):
+        ref = getattr(np, name)(a, axis=0)
+        o = nd.zeros(ref.shape, ref.dtype)
+        ret = getattr(nd, name)(da, axis=0, out=o)
+        assert ret is o and np.allclose(o.get(), ref, rtol=1e-5), name
+        assert getattr(da, name)(axis=0, out=o) is o
+        with pytest.raises(ValueError, match="wrong shape"):
+            getattr(nd, name)(da, axis=0, out=nd.zeros((4,), ref.dtype))
+    with pytest.raises(TypeError, match="Cannot cast"):
+        nd.sum(da, axis=0, out=nd.zeros((5,), np.int32))
+    # unsupported keywords: loud
+    for call in (lambda: nd.add(da, db, where=nd.asarray(a > 0)), lambda: nd.add(da, db, dtype=np.float64), lambda: nd.sum(da, where=nd.asarray(a > 0)),
+                 lambda: nd.sum(da, initial=3.0), lambda: nd.max(da, initial=0.0), lambda: nd.zeros((2, 2), order="F"), lambda: nd.add(da, db, casting="unsafe"),
+                 lambda: nd.concatenate([da, db], dtype=np.float64), lambda: nd.std(da, correction=1), lambda: nd.sin(da, where=False)):
+        with pytest.raises(TypeError, match="not supported"):
+            call()
+    with pytest.raises(TypeError, match="unexpected keyword"):
+        nd.add(da, db, axis=0)
+    # .. at their defaults they pass
+    assert np.array_equal(nd.sum(da, axis=1, where=True, initial=None).get(), a.sum(axis=1))
+    assert nd.zeros((2, 2), order="C", like=None).shape == (2, 2) and da.astype(np.float64, casting="unsafe", order="K").dtype == np.float64
