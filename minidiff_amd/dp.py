@@ -327,7 +327,7 @@ class GradSync:
         if len(self.params) == 1 and self.bucket is None:
             raw = rest[0].grad._data
             if not _is_contiguous(raw):
-                raw = B.copy(raw)
+                raw = B.copy(raw, order="C")
                 self.params[0].grad = self.md.Tensor(raw)
             self._sent.add(id(rest[0]))
             allreduce(raw)

@@ -162,7 +162,7 @@ class HipBackendTable:
                 return loop(arr)
             from .graph import CapturedSweep, can_capture
             if not arr.is_c_contiguous:
-                arr = nd.copy(arr)
+                arr = nd.copy(arr, order="C")
             K = builtins_min(VMAP_ROWS_PER_GRAPH, n)
             key = (arr.shape[1:], arr.dtype, K)
             if state["key"] != key:
@@ -172,7 +172,7 @@ class HipBackendTable:
                 if not can_capture():
                     state["failed"] = True
                     return loop(arr)
-                rows = nd.copy(arr[:K])                      # the resident row buffer: K rows per graph launch
+                rows = nd.copy(arr[:K], order="C")                      # the resident row buffer: K rows per graph launch
 
                 def batch():
                     outs = [nd.asarray(fun(rows[k])) for k in range(K)]

@@ -496,7 +496,7 @@ class DeviceArray(_fp.ArrayBase if _fp is not None else object):
         """D2H copy (synchronises the stream). Large results land in a page-locked block from
         libmdhip's host pool (returned to the pool when the last NumPy view of it dies): a copy into
         fresh pageable memory runs at the page-fault rate, not the link rate."""
-        src = self if self.is_c_contiguous else copy(self)
+        src = self if self.is_c_contiguous else _ccopy(self)
         nbytes = src.size * self.dtype.itemsize
         host = None
         if nbytes >= _PINNED_MIN:
@@ -566,7 +566,7 @@ class DeviceArray(_fp.ArrayBase if _fp is not None else object):
         return astype(self, dtype, copy=copy)
 
     def copy(self, order="C"):
-        return copy(self)
+        return copy(self, order=order)
 
     def reshape(self, *shape, order="C"):
         if len(shape) == 1 and not isinstance(shape[0], (int, np.integer)):
@@ -646,7 +646,7 @@ class DeviceArray(_fp.ArrayBase if _fp is not None else object):
     def __matmul__(self, o): return matmul(self, o)
     def __rmatmul__(self, o): return matmul(o, self)
     def __neg__(self): return negative(self)
-    def __pos__(self): return copy(self)
+    def __pos__(self): return _ccopy(self)
     def __abs__(self): return absolute(self)
     def __invert__(self): return invert(self)
     def __lt__(self, o): return less(self, o)
@@ -1017,7 +1017,7 @@ def _straighten(x):
     if len(st) < 2 or st[-1] == 1 or st[-1] == 0:   # the common case first: this runs on every binary call
         return x
     if x.size >= (1 << 16) and x._expr is None and 1 in st[-3:-1] and x.shape[-1] >= 32:
-        return copy(x)
+        return _ccopy(x)
     return x
 
 
@@ -1075,7 +1075,7 @@ def _unalias(x, out: "DeviceArray"):
     (xl, xh), (ol, oh) = _extent(x), _extent(out)
     if xh < ol or oh < xl:
         return x
-    return copy(x)
+    return _ccopy(x)
 
 
 def _copy_into(dst: DeviceArray, src, shape=None):
@@ -1118,7 +1118,7 @@ def _fill(dst: DeviceArray, value):
 # =============================================================================
 # elementwise API (names follow numpy / the backend table)
 # =============================================================================
-_DEFAULT_KW = {"where": (True,), "subok": (True,), "order": ("K", "C", "A"), "casting": ("same_kind",), "copy": (True,), "initial": (), "like": (),
+_DEFAULT_KW = {"where": (True,), "subok": (True, False), "order": ("K", "C", "A"), "casting": ("same_kind",), "copy": (True,), "initial": (), "like": (),
                "device": (), "signature": (), "mean": (), "correction": (), "out": (), "dtype": (), "ndmin": (0,)}
 
 
@@ -1281,7 +1281,7 @@ def clip(a, a_min=None, a_max=None, **kw):
         touched = True
     if out is not None:
         return _finish_out(res, out, "clip")
-    return res if touched else copy(res)
+    return res if touched else _ccopy(res)
 
 
 def astype(a, dtype, copy=True, **kw):
@@ -1307,8 +1307,8 @@ def _convert(a: "DeviceArray", dtype) -> "DeviceArray":
     return res
 
 
-def copy(a, order="K", **kw):
-    _defaults_only("copy", kw)
+def _ccopy(a):
+    """A C-contiguous copy (ndarray.copy()'s default layout; what every internal "make it dense" wants)."""
     a = asarray(a)
     res = DeviceArray.empty(a.shape, a.dtype)
     if a._code >= _NARROW_MIN:
@@ -1316,6 +1316,56 @@ def copy(a, order="K", **kw):
     else:
         _lib().unary(_capi.U_COPY, a.desc(), res.desc())
     return res
+
+
+def _k_perm(a):
+    """Axes from outermost to innermost in MEMORY — NumPy's order 'K' (nditer's axis ordering for one operand): an insertion sort
+    by |stride| starting from C order in which a stride-0 (broadcast) axis compares as ambiguous and keeps its place."""
+    st = a._strides
+    perm = list(range(a.ndim - 1, -1, -1))          # fastest axis first, as nditer keeps them
+    for i0 in range(1, a.ndim):
+        pos, j0 = i0, perm[i0]
+        for i1 in range(i0 - 1, -1, -1):
+            s0, s1 = st[j0], st[perm[i1]]
+            if s0 == 0 or s1 == 0:
+                continue                            # ambiguous: look further, move only past a definite answer
+            if abs(s1) <= abs(s0):
+                break
+            pos = i1
+        if pos != i0:
+            perm.insert(pos, perm.pop(i0))
+    return tuple(reversed(perm))
+
+
+def _resolve_order(a, order):
+    """NumPy's memory-order argument for an existing array -> 'C', 'F' or 'K' ('A': Fortran only for an array that is
+    F- and not C-contiguous; 'K' of a C- / F-contiguous array is C / F)."""
+    if order not in ("C", "F", "A", "K"):
+        raise ValueError("order must be one of 'C', 'F', 'A', or 'K'")
+    if order in ("A", "K"):
+        if a.is_c_contiguous or a.ndim < 2:
+            return "C"
+        if a.T.is_c_contiguous:
+            return "F"
+        return "C" if order == "A" else "K"
+    return order
+
+
+def copy(a, order="K", **kw):
+    """np.copy: the values, laid out as `order` asks — 'K' (the default) keeps the source's axis order in memory, so a copy of x.T
+    is a streaming copy into the same transposed layout, not a transposing one."""
+    _defaults_only("copy", kw)
+    a = asarray(a)
+    order = _resolve_order(a, order)
+    if order == "C":
+        return _ccopy(a)
+    # (the LAYOUT of a 'K' result follows PyArray_NewLikeArray: axes by descending |stride|, ties in axis order — a broadcast axis
+    # goes innermost; the ORDER 'K' reads elements in is nditer's, _k_perm)
+    perm = tuple(range(a.ndim - 1, -1, -1)) if order == "F" else tuple(sorted(range(a.ndim), key=lambda d: -abs(a._strides[d])))
+    inv = [0] * a.ndim
+    for i, p_ in enumerate(perm):
+        inv[p_] = i
+    return transpose(_ccopy(transpose(a, perm)), inv)
 
 
 # =============================================================================
@@ -1400,10 +1450,10 @@ def reshape(a, shape=None, order="C", newshape=None, **kw):
     a = asarray(a)
     if shape is None:
         shape = newshape
-    if order not in ("C", "A", "K", None):
-        if order == "F":
-            return transpose(reshape(transpose(a), tuple(reversed(_normalize_shape(shape)))))
-        raise ValueError("order must be one of 'C', 'F', 'A', or 'K'")
+    if order == "K":
+        raise ValueError("order 'K' is not permitted for reshaping")
+    if order is not None and _resolve_order(a, order) == "F":      # ('A': Fortran index order only for an F-contiguous array)
+        return transpose(reshape(transpose(a), tuple(reversed(_normalize_shape(shape)))))
     shape = list(_normalize_shape(shape))
     size = a.size
     if shape.count(-1) > 1:
@@ -1425,22 +1475,25 @@ def reshape(a, shape=None, order="C", newshape=None, **kw):
         return a._view(a._offset, shape, _c_strides(shape))
     st = _reshape_view_strides(a.shape, a._strides, shape)
     if st is None:
-        a = copy(a)
+        a = _ccopy(a)
         st = _c_strides(shape)
     return a._view(a._offset, shape, st)
 
 
 def ravel(a, order="C"):
     a = asarray(a)
+    order = _resolve_order(a, order)
     if order == "F":
         return reshape(transpose(a), (-1,))
+    if order == "K":      # memory order of a view that is neither C- nor F-contiguous
+        return reshape(transpose(a, _k_perm(a)), (-1,))
     return reshape(a, (-1,))
 
 
 def flatten(a, order="C"):
     a = asarray(a)
     r = ravel(a, order)
-    return copy(r) if r._buf is a._buf else r
+    return _ccopy(r) if r._buf is a._buf else r
 
 
 def broadcast_to(a, shape, **kw):
@@ -1911,7 +1964,7 @@ def _as3d(x: DeviceArray, batch_shape: tuple):
         if _prod(xb) == 1 or builtins_all(s == 0 for s in full._strides[:-2]):
             st = [0]
         else:
-            full = copy(full)
+            full = _ccopy(full)
             st = [r * c]
     return full._view(full._offset, (B, r, c), (st[0], full._strides[-2], full._strides[-1]))
 
@@ -2086,19 +2139,25 @@ def _like_dtype(a, dtype):
     return np.asarray(a).dtype
 
 
-def zeros_like(a, dtype=None, **kw):
+def _like_shape(a, shape):
+    if shape is not None:
+        return _normalize_shape(shape)
+    return a.shape if isinstance(a, DeviceArray) else np.shape(a)
+
+
+def zeros_like(a, dtype=None, shape=None, **kw):
     _defaults_only("zeros_like", kw)
-    return zeros(np.shape(a) if not isinstance(a, DeviceArray) else a.shape, _like_dtype(a, dtype))
+    return zeros(_like_shape(a, shape), _like_dtype(a, dtype))
 
 
-def ones_like(a, dtype=None, **kw):
+def ones_like(a, dtype=None, shape=None, **kw):
     _defaults_only("ones_like", kw)
-    return ones(np.shape(a) if not isinstance(a, DeviceArray) else a.shape, _like_dtype(a, dtype))
+    return ones(_like_shape(a, shape), _like_dtype(a, dtype))
 
 
-def full_like(a, fill_value, dtype=None, **kw):
+def full_like(a, fill_value, dtype=None, shape=None, **kw):
     _defaults_only("full_like", kw)
-    return full(np.shape(a) if not isinstance(a, DeviceArray) else a.shape, fill_value, _like_dtype(a, dtype))
+    return full(_like_shape(a, shape), fill_value, _like_dtype(a, dtype))
 
 
 def arange(*args, dtype=None, **kw):
@@ -2197,7 +2256,7 @@ def tile(A, reps):
         for ax, r in enumerate(reps):
             if r != 1:
                 res = concatenate([res] * r, axis=ax) if r > 0 else res._view(res._offset, res.shape[:ax] + (0,) + res.shape[ax + 1:], res._strides)
-        return copy(res) if res is A else res
+        return _ccopy(res) if res is A else res
     # (r0, a0, r1, a1, ...) broadcast view -> one strided copy
     ishape, istr = [], []
     for r, n, s in zip(reps, A.shape, A._strides):
@@ -2225,7 +2284,7 @@ def repeat(a, repeats, axis=None):
         if len(shp) > MAX_NDIM:
             raise ValueError("repeat: rank too large for the device descriptor")
         view = a._view(a._offset, shp, st)
-        res = copy(view)
+        res = _ccopy(view)
         fshape = a.shape[:ax] + (a.shape[ax] * r,) + a.shape[ax + 1:]
         return res._view(res._offset, fshape, _c_strides(fshape))
     idx = np.repeat(np.arange(a.shape[ax]), np.asarray(repeats))
@@ -2266,7 +2325,7 @@ def flatnonzero(a) -> "DeviceArray":
     (count -> scan -> ordered compaction; one host sync for the data-dependent size)."""
     a = asarray(a)
     if not a.is_c_contiguous:
-        a = copy(a)
+        a = _ccopy(a)
     cnt = C.c_int64()
     _lib().nonzero_count(a.desc(), C.byref(cnt))
     res = DeviceArray.empty((cnt.value,), np.int64)
@@ -2597,20 +2656,24 @@ def argwhere(a):
     return stack(list(nonzero(a)), axis=1)
 
 
-def isin(element, test_elements, **kw):
-    if kw:
-        raise TypeError("isin: only the default options are supported on the device")
+def isin(element, test_elements, assume_unique=False, invert=False, kind=None):
+    """np.isin: `assume_unique` and `kind` only choose NumPy's algorithm (same answer); `invert` negates it."""
+    if kind not in (None, "sort", "table"):
+        raise ValueError(f"Invalid kind: '{kind}'. Please use None, 'sort' or 'table'.")
     e = asarray(element)
     t = ravel(asarray(test_elements))
     if t.size == 0:
-        return zeros(e.shape, dtype=np.bool_)
+        return full(e.shape, py_bool(invert), dtype=np.bool_)
     eq = equal(expand_dims(e, e.ndim), reshape(t, (1,) * e.ndim + (t.size,)))
-    return any(eq, axis=e.ndim)
+    res = any(eq, axis=e.ndim)
+    return logical_not(res) if invert else res
 
 
 def unravel_index(indices, shape, order="C"):
+    if order == "F":      # column-major: the C decomposition over the reversed shape, coordinates handed back in axis order
+        return tuple(reversed(unravel_index(indices, tuple(reversed(_normalize_shape(shape))), "C")))
     if order != "C":
-        raise ValueError("unravel_index: only order='C' is supported on the device")
+        raise ValueError("only 'C' or 'F' order is permitted")
     idx = asarray(indices)
     if idx.dtype.kind not in "iu":
         raise TypeError("only int indices permitted")

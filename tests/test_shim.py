@@ -173,3 +173,51 @@ def test_keywords_are_honoured_or_refused_never_dropped(lib):
     # .. at their defaults they pass
     assert np.array_equal(nd.sum(da, axis=1, where=True, initial=None).get(), a.sum(axis=1))
     assert nd.zeros((2, 2), order="C", like=None).shape == (2, 2) and da.astype(np.float64, casting="unsafe", order="K").dtype == np.float64
+
+
+def test_memory_order_arguments_follow_numpy(lib):
+    """`order=` of ravel / flatten / copy / reshape / unravel_index on views of every kind (transposed, permuted, sliced, reversed,
+    broadcast): the VALUES NumPy returns — 'A' and 'K' depend on the view's strides — and, for copies, NumPy's result layout (a 'K'
+    copy of x.T is laid out like x.T). isin's and the *_like functions' keywords."""
+    from minidiff_amd import ndarray as nd
+    a = np.arange(24.).reshape(2, 3, 4)
+    d = nd.asarray(a)
+    views = {"T": (d.T, a.T), "swap": (nd.swapaxes(d, 0, 1), np.swapaxes(a, 0, 1)), "slice": (d[:, ::2, 1:], a[:, ::2, 1:]),
+             "perm": (nd.transpose(d, (1, 2, 0)), np.transpose(a, (1, 2, 0))), "neg": (d[::-1].T, a[::-1].T), "plain": (d, a),
+             "bcast": (nd.broadcast_to(d[:, :1, :], (2, 3, 4)), np.broadcast_to(a[:, :1, :], (2, 3, 4)))}
+
+    def same(got, exp, what, layout=False):
+        assert got.dtype == exp.dtype and np.array_equal(got.get(), exp), what
+        if layout:
+            assert got.is_c_contiguous == exp.flags.c_contiguous and got.T.is_c_contiguous == exp.flags.f_contiguous, what
+
+    for vn, (dv, av) in views.items():
+        for order in "CFAK":
+            same(nd.ravel(dv, order=order), np.ravel(av, order=order), ("ravel", vn, order))
+            same(nd.flatten(dv, order=order), av.flatten(order=order), ("flatten", vn, order))
+            same(nd.copy(dv, order=order), np.copy(av, order=order), ("copy", vn, order), layout=True)
+            same(dv.copy(order=order), av.copy(order=order), ("method copy", vn, order), layout=True)
+            if order != "K":
+                same(nd.reshape(dv, (av.size // 6, 6), order=order), np.reshape(av, (av.size // 6, 6), order=order), ("reshape", vn, order))
+        same(nd.copy(dv), np.copy(av), ("copy default", vn), layout=True)        # np.copy: 'K'
+        same(dv.copy(), av.copy(), ("method copy default", vn), layout=True)     # ndarray.copy: 'C'
+    with pytest.raises(ValueError):
+        nd.reshape(d, (4, 6), order="K")
+    with pytest.raises(ValueError):
+        nd.ravel(d, order="Z")
+    idx = np.array([5, 7, 23, 0])
+    for order in "CF":
+        for g, e in zip(nd.unravel_index(nd.asarray(idx), (2, 3, 4), order=order), np.unravel_index(idx, (2, 3, 4), order=order)):
+            assert np.array_equal(g.get(), e), order
+    with pytest.raises(ValueError):
+        nd.unravel_index(nd.asarray(idx), (2, 3, 4), order="K")
+    te = np.array([1., 5., 30.])
+    for kw in ({}, {"invert": True}, {"assume_unique": True}, {"kind": "sort"}, {"invert": True, "assume_unique": True}):
+        same(nd.isin(d, nd.asarray(te), **kw), np.isin(a, te, **kw), ("isin", kw))
+    same(nd.isin(d, nd.asarray(np.array([])), invert=True), np.isin(a, np.array([]), invert=True), "isin empty")
+    with pytest.raises(ValueError):
+        nd.isin(d, nd.asarray(te), kind="bogus")
+    for f in ("zeros_like", "ones_like"):
+        same(getattr(nd, f)(d, shape=(2, 2)), getattr(np, f)(a, shape=(2, 2)), f)
+        same(getattr(nd, f)(d, subok=False, dtype=np.int32), getattr(np, f)(a, subok=False, dtype=np.int32), f)
+    same(nd.full_like(d, 3, shape=5), np.full_like(a, 3, shape=5), "full_like")
