@@ -640,6 +640,9 @@ class DeviceArray(_fp.ArrayBase if _fp is not None else object):
     def __floordiv__(self, o): return floor_divide(self, o)
     def __rfloordiv__(self, o): return floor_divide(o, self)
     def __mod__(self, o): return mod(self, o)
+    def __divmod__(self, o): return floor_divide(self, o), mod(self, o)
+    def __rdivmod__(self, o): return floor_divide(o, self), mod(o, self)
+    def __contains__(self, v): return py_bool(any(equal(self, v)).item())
     def __rmod__(self, o): return mod(o, self)
     def __pow__(self, o): return power(self, o)
     def __rpow__(self, o): return power(o, self)
@@ -704,6 +707,8 @@ def _scalar_desc(value, code: int) -> ArrayDesc:
         d.scalar_f = float(value)
     else:
         v = int(value)
+        if not (_INT64_MIN <= v < (1 << 64)):
+            raise OverflowError(f"Python integer {v} does not fit a 64-bit scalar operand")      # (backstop: callers range-check first)
         if v > _INT64_MAX:      # a uint64 value >= 2**63 travels as its bits, under the uint64 code (md_scalar_as reads it unsigned)
             d.dtype = _capi.U64
             v -= 1 << 64
@@ -1000,12 +1005,10 @@ def _value_desc(v, dt) -> ArrayDesc:
     """Scalar descriptor of a value assigned / added into an array of dtype `dt` (NEP 50: a Python int must fit `dt`)."""
     if isinstance(v, np.generic):
         v = v.item()
+    elif type(v) is int:
+        v = _py_int_for(dt, v)
     if isinstance(v, (float, complex)):
         return _scalar_desc(v, _capi.F64)
-    if isinstance(v, int) and not isinstance(v, py_bool) and dt.kind in "iu":
-        info = np.iinfo(dt)
-        if not (info.min <= v <= info.max):
-            raise OverflowError(f"Python integer {v} out of bounds for {dt}")
     return _scalar_desc(v, _capi.I64)
 
 
@@ -1078,8 +1081,36 @@ def _unalias(x, out: "DeviceArray"):
     return _ccopy(x)
 
 
+def _py_int_for(dt, v):
+    """A Python int on its way into an array of dtype `dt` (NEP 50): it must FIT an integer type (OverflowError otherwise); beyond
+    64 bits it reaches a float array as the float it rounds to and a bool array as True — never as wrapped bits."""
+    if dt.kind in "iu":
+        info = np.iinfo(dt)
+        if not (info.min <= v <= info.max):
+            raise OverflowError(f"Python integer {v} out of bounds for {dt}")
+    elif not (_INT64_MIN <= v <= _INT64_MAX):
+        return py_bool(v) if dt.kind == "b" else float(v)
+    return v
+
+
+def _py_int_wrapped(dt, v):
+    """.. and where NumPy CASTS a Python int instead (np.where, ufunc.at): modulo 2**bits into an integer type."""
+    if dt.kind in "iu":
+        info = np.iinfo(dt)
+        if not (_INT64_MIN <= v < (1 << 64)):       # (NumPy converts to a C integer first: beyond 64 bits even a cast raises)
+            raise OverflowError("Python int too large to convert to C long")
+        if not (info.min <= v <= info.max):
+            v &= (1 << info.bits) - 1
+            if dt.kind == "i" and v > info.max:
+                v -= 1 << info.bits
+        return v
+    return _py_int_for(dt, v)
+
+
 def _copy_into(dst: DeviceArray, src, shape=None):
     """dst[...] = src with broadcasting and dtype conversion (unary COPY kernel)."""
+    if type(src) is int:
+        src = _py_int_for(dst.dtype, src)
     _before_write(dst)
     if dst._code >= _NARROW_MIN or (isinstance(src, DeviceArray) and src._code >= _NARROW_MIN) or (isinstance(src, np.generic) and src.dtype in _narrow._WIDE):
         if not isinstance(src, DeviceArray):     # a scalar: through a 0-d array of its own (or the default) type
@@ -1104,6 +1135,8 @@ def _copy_into(dst: DeviceArray, src, shape=None):
 
 def _fill(dst: DeviceArray, value):
     _before_write(dst)
+    if type(value) is int:
+        value = _py_int_for(dst.dtype, value)      # (a NumPy scalar converts instead)
     if isinstance(value, DeviceArray) or dst._code >= _NARROW_MIN:
         _copy_into(dst, value)
         return
@@ -1258,6 +1291,11 @@ def where(condition, x=None, y=None):
                 return res
     res = DeviceArray._new(shape, odt)
     dc = _operand_desc(c, shape, _capi.I64)
+    # (np.where is not a ufunc: a Python int beyond the result type is CAST, wrapping, where a ufunc would raise OverflowError)
+    if type(a) is int:
+        a = _py_int_wrapped(odt, a)
+    if type(b) is int:
+        b = _py_int_wrapped(odt, b)
     da = _operand_desc(a, shape, 0 if isinstance(a, DeviceArray) else _scalar_code(a, odt))
     db = _operand_desc(b, shape, 0 if isinstance(b, DeviceArray) else _scalar_code(b, odt))
     _lib().where(dc, da, db, res.desc())
@@ -1539,6 +1577,8 @@ def squeeze(a, axis=None):
     if axis is None:
         keep = [i for i, n in enumerate(a.shape) if n != 1]
     else:
+        if isinstance(axis, list):
+            raise TypeError("'list' object cannot be interpreted as an integer")
         axes = normalize_axes(axis, a.ndim)
         for ax in axes:
             if a.shape[ax] != 1:
@@ -1587,8 +1627,18 @@ def atleast_3d(a):
 # =============================================================================
 # reductions
 # =============================================================================
+def _reduce_axes(axis, a):
+    """`axis` of a ufunc.reduce-style call: ints and tuples of ints (a list is a TypeError in NumPy); a 0-d operand takes 0 / -1."""
+    if isinstance(axis, list):
+        raise TypeError("'list' object cannot be interpreted as an integer")
+    if a.ndim == 0 and isinstance(axis, (int, np.integer)) and not isinstance(axis, py_bool) and axis in (0, -1):
+        return None
+    return axis
+
+
 def _reduce(code, a, axis, keepdims, out_dtype):
     a = asarray(a)
+    axis = _reduce_axes(axis, a)
     axes = normalize_axes(axis, a.ndim)
     mask = 0
     for ax in axes:
@@ -1877,6 +1927,8 @@ def argmin(a, axis=None, out=None, keepdims=False, **kw):
 
 
 def _count(a, axis):
+    if isinstance(axis, list):
+        raise TypeError("'list' object cannot be interpreted as an integer")
     axes = normalize_axes(axis, a.ndim)
     n = 1
     for ax in axes:
@@ -1892,6 +1944,10 @@ def mean(a, axis=None, dtype=None, out=None, keepdims=False, **kw):
     if dtype is None and a.dtype.kind in "bi":
         dtype = np.dtype(np.float64)
     s = sum(a, axis=axis, dtype=dtype, keepdims=keepdims)
+    if s.dtype.kind in "iub":
+        # an integer dtype= : NumPy divides with casting='unsafe' back into the integer sum (the quotient truncates toward zero)
+        with np.errstate(all="ignore"):
+            return _finish_out(astype(_binary(np.true_divide, _capi.B_TRUE_DIV, s, n), s.dtype), out, "mean")
     return _finish_out(_binary(np.true_divide, _capi.B_TRUE_DIV, s, n, out=s), out, "mean")
 
 
@@ -2549,6 +2605,10 @@ def _scatter(a: DeviceArray, key, value, mode):
         if mode == _capi.SCATTER_SET:
             _copy_into(dst, value)
         else:
+            if type(value) is int:
+                value = _py_int_wrapped(dst.dtype, value)      # (ufunc.at casts its scalar operand)
+            elif type(value) is float and dst.dtype.kind in "iu" and value == value and abs(value) < 2.0 ** 63:
+                value = int(value)                             # (.. a float too: toward zero, then the integer add)
             _binary(np.add, _capi.B_ADD, dst, value, out=dst)
         return
     plan, out_shape, base_ptr, keep = _build_plan(a, entries)
@@ -2561,6 +2621,8 @@ def _scatter(a: DeviceArray, key, value, mode):
             v = v._view(v._offset, v.shape[1:], v._strides[1:])
         vd = v.desc(out_shape)
     else:
+        if type(v) is int and mode == _capi.SCATTER_ADD:
+            v = _py_int_wrapped(a.dtype, v)      # (ufunc.at casts its scalar operand; an assignment checks it)
         vd = _value_desc(v, a.dtype)
     if _prod(out_shape):
         _lib().scatter(plan, base_ptr, a._code, vd, mode)
