@@ -2423,9 +2423,10 @@ def _parse_key(a: DeviceArray, key):
                 k = DeviceArray.from_numpy(k.astype(np.int64))
             else:
                 raise IndexError("arrays used as indices must be of integer (or boolean) type")
-        if isinstance(k, DeviceArray) and k.dtype == np.bool_:
-            if k.ndim == 0:
-                raise IndexError("0-d boolean indices are not supported on the device")
+        if isinstance(k, (py_bool, np.bool_)) or (isinstance(k, DeviceArray) and k.dtype == np.bool_ and k.ndim == 0):
+            # a scalar boolean consumes no axis: it ADDS one, of length 1 (True) or 0 (False) — NumPy's 0-d boolean index
+            expanded.append(("bool0", py_bool(k.item() if isinstance(k, DeviceArray) else k)))
+        elif isinstance(k, DeviceArray) and k.dtype == np.bool_:
             expanded.append(("bool", k))
         else:
             expanded.append(k)
@@ -2435,6 +2436,8 @@ def _parse_key(a: DeviceArray, key):
             continue
         if isinstance(k, tuple) and k[0] == "bool":
             n_consume += k[1].ndim
+        elif isinstance(k, tuple) and k[0] == "bool0":
+            pass
         else:
             n_consume += 1
     if builtins_sum(1 for k in expanded if k is Ellipsis) > 1:
@@ -2452,9 +2455,11 @@ def _parse_key(a: DeviceArray, key):
             entries.append(("new",))
         elif isinstance(k, slice):
             entries.append(("slice", k))
+        elif isinstance(k, tuple) and k[0] == "bool0":
+            entries.append(("new",) if k[1] else ("new0",))
         elif isinstance(k, tuple) and k[0] == "bool":
             m = k[1]
-            ax0 = builtins_sum(1 for e in entries if e[0] != "new")
+            ax0 = builtins_sum(1 for e in entries if e[0] not in ("new", "new0"))
             if m.shape != a.shape[ax0:ax0 + m.ndim]:
                 raise IndexError(f"boolean index did not match indexed array along axis {ax0}; size of axis is {a.shape[ax0]} but size of corresponding boolean axis is {m.shape[0]}")
             for ix in nonzero(m):
@@ -2474,6 +2479,8 @@ def _parse_key(a: DeviceArray, key):
                 raise IndexError("only integers, slices (`:`), ellipsis (`...`), numpy.newaxis (`None`) and integer or boolean arrays are valid indices")
     if not saw_ellipsis:
         entries += [("slice", slice(None))] * (a.ndim - n_consume)
+    if has_adv and builtins_any(isinstance(k, tuple) and k[0] == "bool0" for k in expanded):
+        raise IndexError("a scalar boolean index together with index arrays is not supported on the device")
     return entries, has_adv
 
 
@@ -2483,8 +2490,8 @@ def _basic_view(a: DeviceArray, entries):
     ax = 0
     for e in entries:
         kind = e[0]
-        if kind == "new":
-            shape.append(1)
+        if kind == "new" or kind == "new0":
+            shape.append(1 if kind == "new" else 0)
             strides.append(0)
             continue
         n, s = a.shape[ax], a._strides[ax]
@@ -2515,7 +2522,11 @@ def _build_plan(a: DeviceArray, entries):
     bshape = ()
     for ix in idx_arrays:
         if ix is not None:
-            bshape = _broadcast_shapes(bshape, ix.shape)
+            try:
+                bshape = _broadcast_shapes(bshape, ix.shape)
+            except ValueError:
+                raise IndexError("shape mismatch: indexing arrays could not be broadcast together with shapes "
+                                 + " ".join(str(tuple(x.shape)) for x in idx_arrays if x is not None)) from None
     adjacent = builtins_all(entries[i][0] in ("adv", "int") for i in range(adv_pos[0], adv_pos[-1] + 1))
     # walk entries, collecting slice dims and per-index (axis extent, stride)
     off = a._offset
@@ -2712,9 +2723,8 @@ def put_along_axis(arr, indices, values, axis):
 # ---- index utilities (device integer arithmetic) ---------------------------------------
 def argwhere(a):
     a = asarray(a)
-    if a.ndim == 0:
-        a = reshape(a, (1,))
-        return reshape(stack(list(nonzero(a)), axis=1), (-1, 0))
+    if a.ndim == 0:      # (NumPy: one row of no coordinates for a non-zero scalar, none for zero)
+        return zeros((1 if py_bool(a.item()) else 0, 0), dtype=np.int64)
     return stack(list(nonzero(a)), axis=1)
 
 

@@ -213,7 +213,74 @@ def _python_scalars_into_arrays(nd):
     t.done()
 
 
-CASES = {"reductions_binaries": _reductions_and_binaries, "layout_creation_products": _layout_creation_products, "python_scalars": _python_scalars_into_arrays}
+def _indexing(nd):
+    """Key forms of a[key], a[key] = v and np.add.at: ints, slices, Ellipsis, None, index arrays (broadcast, negative, empty, mixed with
+    slices, separated), boolean masks of every rank, SCALAR booleans (they add an axis of length 1 / 0), lists, NumPy scalars, bad
+    keys; value shapes that do not broadcast; 0-d arrays; take / put_along_axis; nonzero / argwhere."""
+    t = Probe()
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((4, 5, 6)); d = nd.asarray(a)
+
+    def dev(k):
+        if isinstance(k, tuple):
+            return tuple(dev(x) for x in k)
+        return nd.asarray(k) if isinstance(k, np.ndarray) else k
+
+    i1 = np.array([0, 2, 3]); i2 = np.array([[0, 1], [2, 3]]); neg = np.array([-1, -4, 0]); m3 = a > 0
+    m1 = np.array([True, False, True, True]); m2 = rng.random((4, 5)) > 0.5
+    keys = [0, -1, 4, -5, (1, 2), (1, 2, 3), (1, 2, 3, 4), slice(None), slice(1, 3), slice(None, None, -1), slice(None, None, 2), slice(5, 1, -2), slice(10, 20),
+            (slice(None), 0), (0, slice(None), -1), Ellipsis, (Ellipsis, 0), (0, Ellipsis), (Ellipsis, 0, Ellipsis), None, (None, 0), (0, None, Ellipsis, None),
+            (slice(None), None, 1), i1, (i1,), (i1, i1), (i1, slice(None), i1), (slice(None), i1), (slice(None), i1, i1), (i2,), (i2, i1[:2]), (i1, 0), (0, i1),
+            (i1, None), (None, i1), (Ellipsis, i1), neg, np.array([4]), np.array([-5]), np.array([], dtype=np.int64), (np.array([0, 1]), np.array([0, 1, 2])),
+            m3, m1, (m1,), (m1, 0), (slice(None), m2[0]), m2, (m2, 0), (0, m2[0]), np.array([True, False]), (m1, i1), (m1, i1[:3]),
+            [0, 2], [[0, 1], [1, 2]], [True, False, True, True], (0, [1, 2]), ([0, 1], [1, 2]),
+            np.int64(2), np.array(2), True, False, np.True_, (slice(None), True), (np.array(1), np.array(2)), 1.5, np.array([1.5]), "x", (slice(None),) * 4,
+            np.array([[True, False, True, False, True]] * 4)]
+    for k in keys:
+        t(f"getitem {k!r:.60}", lambda: d[dev(k)], lambda: a[k])
+        for val, vn in ((7.0, "scalar"), (np.float32(2.0), "npscalar"), (None, "bcast")):
+            def setit(arr, lib):
+                arr = arr.copy()
+                kk = dev(k) if lib is nd else k
+                if vn == "bcast":
+                    shp = a[k].shape
+                    v = np.arange(int(np.prod(shp)), dtype=np.float64).reshape(shp) if len(shp) else 3.0
+                    arr[kk] = lib.asarray(v) if lib is nd and isinstance(v, np.ndarray) else v
+                else:
+                    arr[kk] = val
+                return arr
+            t(f"setitem {vn} {k!r:.60}", lambda: setit(d, nd), lambda: setit(a, np))
+
+        def addat(arr, lib):
+            arr = arr.copy()
+            (lib.index_add if lib is nd else np.add.at)(arr, dev(k) if lib is nd else k, 1.5)
+            return arr
+        t(f"add.at {k!r:.60}", lambda: addat(d, nd), lambda: addat(a, np))
+    for k, shape in ((slice(0, 2), (3, 5, 6)), (i1, (2, 5, 6)), ((i1, i1), (2, 6)), (m1, (2, 5, 6)), (0, (5,)), ((slice(None), 0), (4, 1, 6))):
+        t(f"setitem bad shape {k!r:.40}", lambda: d.copy().__setitem__(dev(k), nd.asarray(np.ones(shape))), lambda: a.copy().__setitem__(k, np.ones(shape)))
+    z = np.float64(3.0); dz = nd.asarray(z)
+    for k in ((), Ellipsis, None, 0, True, np.array(True), slice(None)):
+        t(f"0d getitem {k!r}", lambda: dz[dev(k)], lambda: np.asarray(z)[k])
+    for ax in (0, 1, -1, None, 3):
+        idx = rng.integers(0, 4, (4, 5, 6)) if ax is not None else rng.integers(0, 120, (7,))
+        t(f"take_along {ax}", lambda: nd.take_along_axis(d, nd.asarray(idx), ax), lambda: np.take_along_axis(a, idx, ax))
+
+        def put(arr, lib):
+            arr = arr.copy()
+            lib.put_along_axis(arr, lib.asarray(idx), 9.0, ax)
+            return arr
+        t(f"put_along {ax}", lambda: put(d, nd), lambda: put(a, np))
+    t("take_along bad ndim", lambda: nd.take_along_axis(d, nd.asarray(i1), 0), lambda: np.take_along_axis(a, i1, 0))
+    t("take_along float idx", lambda: nd.take_along_axis(d, nd.asarray(a), 0), lambda: np.take_along_axis(a, a, 0))
+    t("take_along oob", lambda: nd.take_along_axis(d, nd.asarray(np.full((4, 5, 6), 9)), 0), lambda: np.take_along_axis(a, np.full((4, 5, 6), 9), 0))
+    for f in ("nonzero", "argwhere"):
+        for A in (a > 0.5, (a > 5), a, np.float64(2.0), np.float64(0.0), np.zeros((0, 3))):
+            t(f"{f} {A.shape}", lambda: getattr(nd, f)(nd.asarray(A)), lambda: getattr(np, f)(A))
+    t.done()
+
+
+CASES = {"reductions_binaries": _reductions_and_binaries, "layout_creation_products": _layout_creation_products, "python_scalars": _python_scalars_into_arrays,
+         "indexing": _indexing}
 
 
 @pytest.mark.parametrize("name", CASES)
