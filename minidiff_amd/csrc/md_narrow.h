@@ -75,6 +75,12 @@ template <> struct md_carrier_type<MDHIP_F64> { using type = double; };
 static inline mdhip_array md_scalar_in_loop_dtype(const mdhip_array *s, int cdt) {
   mdhip_array r = *s;
   if (s->is_scalar && cdt == MDHIP_F16 && md_dtype_is_float(s->dtype)) r.scalar_f = md_half_to_double(md_double_to_half(s->scalar_f));
+  if (s->is_scalar && cdt == MDHIP_F16 && (s->dtype == MDHIP_I64 || s->dtype == MDHIP_U64 || s->dtype == MDHIP_I32)) {
+    // .. a Python int too: float16(70000) is inf before the arithmetic sees it
+    const double v = s->dtype == MDHIP_U64 ? (double)(uint64_t)s->scalar_i : (double)s->scalar_i;
+    r.dtype = MDHIP_F64;
+    r.scalar_f = md_half_to_double(md_double_to_half(v));
+  }
   if (s->is_scalar && cdt == MDHIP_F32 && md_dtype_is_float(s->dtype)) r.scalar_f = (double)(float)s->scalar_f;
   return r;
 }

@@ -279,12 +279,72 @@ def _indexing(nd):
     t.done()
 
 
+def _promotion_matrix(nd):
+    """Every pair of the twelve dtypes (+ Python / NumPy scalars on either side, small and beyond the narrow types' range) through
+    sixteen binary functions, the in-place forms (same casting errors) and twelve unary ones: result dtype and values."""
+    import warnings
+    t = Probe()
+    DT = [np.bool_, np.int8, np.int16, np.int32, np.int64, np.uint8, np.uint16, np.uint32, np.uint64, np.float16, np.float32, np.float64]
+    rng = np.random.default_rng(3)
+
+    def mk(dt):
+        if dt is np.bool_:
+            return rng.random((3, 4)) > 0.5
+        if np.dtype(dt).kind == "f":
+            return (rng.standard_normal((3, 4)) * 3).astype(dt)
+        if np.dtype(dt).kind == "u":
+            return rng.integers(1, 9, (3, 4)).astype(dt)
+        return rng.integers(-6, 7, (3, 4)).astype(dt)
+
+    arrs = {dt: mk(dt) for dt in DT}
+    dev = {dt: nd.asarray(v) for dt, v in arrs.items()}
+    OPS = ("add", "subtract", "multiply", "true_divide", "floor_divide", "mod", "power", "maximum", "minimum", "less", "greater_equal", "equal", "not_equal",
+           "logical_and", "logical_or", "logical_xor")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for op in OPS:
+            for da in DT:
+                for db in DT:
+                    A, B = arrs[da], arrs[db]
+                    if op == "power" and np.dtype(db).kind != "b":
+                        B = np.abs(B).astype(db)
+                    t(f"{op} {np.dtype(da).name} {np.dtype(db).name}", lambda: getattr(nd, op)(dev[da], nd.asarray(B)), lambda: getattr(np, op)(A, B))
+                    if op in ("add", "multiply", "true_divide", "floor_divide", "power", "maximum"):
+                        def ip(x, y, lib):
+                            x = x.copy()
+                            getattr(lib, op)(x, y, out=x)
+                            return x
+                        t(f"inplace {op} {np.dtype(da).name} {np.dtype(db).name}", lambda: ip(dev[da], nd.asarray(B), nd), lambda: ip(A, B, np))
+                for sc in (2, -3, 2.5, True, np.float32(1.5), np.int8(2), np.uint8(3), np.float16(0.5), np.int64(5), np.float64(2.0), 200, -200, 70000, 2 ** 31, 2 ** 32, 2 ** 33):
+                    if op == "power" and isinstance(sc, (int, np.integer)) and not isinstance(sc, bool) and (sc < 0 or abs(sc) > 100):
+                        continue
+                    A = arrs[da]
+                    t(f"{op} {np.dtype(da).name} scalar {sc!r}", lambda: getattr(nd, op)(dev[da], sc), lambda: getattr(np, op)(A, sc))
+                    t(f"{op} scalar {sc!r} {np.dtype(da).name}", lambda: getattr(nd, op)(sc, dev[da]), lambda: getattr(np, op)(sc, A))
+        for u in ("negative", "absolute", "sign", "sqrt", "exp", "log", "sin", "tanh", "ceil", "floor", "logical_not", "invert"):
+            for da in DT:
+                t(f"{u} {np.dtype(da).name}", lambda: getattr(nd, u)(dev[da]), lambda: getattr(np, u)(arrs[da]))
+    t.done()
+
+
 CASES = {"reductions_binaries": _reductions_and_binaries, "layout_creation_products": _layout_creation_products, "python_scalars": _python_scalars_into_arrays,
-         "indexing": _indexing}
+         "indexing": _indexing, "promotion_matrix": _promotion_matrix}
 
 
+@pytest.fixture
+def lazy_mode(request):
+    from minidiff_amd import ndarray as nd
+    prev = nd.set_lazy(request.param == "lazy")
+    yield request.param
+    nd.set_lazy(prev)
+
+
+MODES = pytest.mark.parametrize("lazy_mode", ["eager", "lazy"], indirect=True)     # (lazy: fused elementwise chains, minidiff_amd/lazy.py)
+
+
+@MODES
 @pytest.mark.parametrize("name", CASES)
-def test_api_differential_cpu(lib, on_gpu, name):
+def test_api_differential_cpu(lib, on_gpu, name, lazy_mode):
     if on_gpu:
         pytest.skip("other twin")
     from minidiff_amd import ndarray as nd
@@ -292,8 +352,9 @@ def test_api_differential_cpu(lib, on_gpu, name):
 
 
 @gpu
+@MODES
 @pytest.mark.parametrize("name", CASES)
-def test_api_differential_gpu(lib, on_gpu, name):
+def test_api_differential_gpu(lib, on_gpu, name, lazy_mode):
     assert on_gpu
     from minidiff_amd import ndarray as nd
     CASES[name](nd)
