@@ -212,6 +212,14 @@ def normalize_axis(axis, ndim) -> int:
     return ax + ndim if ax < 0 else ax
 
 
+def _comparable(o) -> py_bool:
+    """`array == o` for an `o` that is no number and no array of numbers (None, a string, an arbitrary object) is all False in
+    NumPy (elementwise comparison with an object), not an error."""
+    if o is None or isinstance(o, (str, bytes)):
+        return False
+    return True
+
+
 def normalize_axes(axis, ndim) -> tuple:
     if axis is None:
         return tuple(range(ndim))
@@ -534,6 +542,20 @@ class DeviceArray(_fp.ArrayBase if _fp is not None else object):
     def __repr__(self):
         return repr(self.get()).replace("array(", "DeviceArray(", 1)
 
+    def __str__(self):
+        return str(self.get())
+
+    def __format__(self, spec):
+        return format(self.get()[()] if self.ndim == 0 else self.get(), spec)
+
+    def __round__(self, ndigits=None):
+        return round(self._scalar(), ndigits) if ndigits is not None else round(self._scalar())
+
+    def _scalar(self):
+        if self.size != 1:
+            raise TypeError("only length-1 arrays can be converted to Python scalars")
+        return self.item()
+
     def __len__(self):
         if not self.shape:
             raise TypeError("len() of unsized object")
@@ -545,10 +567,13 @@ class DeviceArray(_fp.ArrayBase if _fp is not None else object):
         return py_bool(self.item())
 
     def __float__(self):
-        return float(self.item())
+        return float(self._scalar())
 
     def __int__(self):
-        return int(self.item())
+        return int(self._scalar())
+
+    def __complex__(self):
+        return complex(self._scalar())
 
     def __index__(self):
         if self.size != 1 or self.dtype.kind not in "iu":
@@ -656,8 +681,8 @@ class DeviceArray(_fp.ArrayBase if _fp is not None else object):
     def __le__(self, o): return less_equal(self, o)
     def __gt__(self, o): return greater(self, o)
     def __ge__(self, o): return greater_equal(self, o)
-    def __eq__(self, o): return equal(self, o)
-    def __ne__(self, o): return not_equal(self, o)
+    def __eq__(self, o): return equal(self, o) if _comparable(o) else full(self.shape, False, dtype=np.bool_)
+    def __ne__(self, o): return not_equal(self, o) if _comparable(o) else full(self.shape, True, dtype=np.bool_)
     def __and__(self, o): return logical_and(self, o) if self.dtype == np.bool_ else NotImplemented
     def __or__(self, o): return logical_or(self, o) if self.dtype == np.bool_ else NotImplemented
     def __xor__(self, o): return logical_xor(self, o) if self.dtype == np.bool_ else NotImplemented

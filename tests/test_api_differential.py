@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 gpu = pytest.mark.gpu
+pytestmark = pytest.mark.filterwarnings("ignore::RuntimeWarning")
 
 
 def _host(x):
@@ -327,8 +328,102 @@ def _promotion_matrix(nd):
     t.done()
 
 
+def _table_helpers_rng_methods(nd):
+    """The table's helper entries (tensor_*, len, repr, array, as_numpy, save / load), its random functions (a seed gives NumPy's
+    numbers: minidiff/backend/numpy.py:131-137) and the methods / conversions of the array class against ndarray's."""
+    import os
+    import tempfile
+    from minidiff_amd.hip_backend import HipBackendTable as T
+    t = Probe()
+    a=np.arange(12.).reshape(3,4); d=nd.asarray(a)
+    def seeded(f):
+        np.random.seed(1234); return f()
+    for name,args in (("randn",(3,4)),("randn",()),("rand",(2,3)),("rand",(5,)),("randint",(5,)),("randint",(2,9,(3,2))),("randint",(0,5,None)),("binomial",(10,0.3,(4,))),("binomial",(5,0.5)),
+                      ("permutation",(7,)),("permutation",(np.arange(5.),)),("choice",(5,3)),("choice",(np.arange(4.),2,False)),("choice",(6,)),("choice",(5,3,True,[0.1,0.2,0.3,0.2,0.2]))):
+        def dev(): 
+            aa=[nd.asarray(x) if isinstance(x,np.ndarray) else x for x in args]
+            return seeded(lambda: getattr(T,name)(*aa))
+        t(f"{name} {args!r:.50}", dev, lambda: seeded(lambda: getattr(np.random,name)(*args)))
+    def shuf(lib):
+        x = lib.asarray(np.arange(10.)) if lib is nd else np.arange(10.)
+        np.random.seed(7); (T.shuffle if lib is nd else np.random.shuffle)(x); return x
+    t("shuffle", lambda: shuf(nd), lambda: shuf(np))
+    x2=np.arange(12.).reshape(4,3)
+    def shuf2(lib):
+        x = lib.asarray(x2.copy()) if lib is nd else x2.copy()
+        np.random.seed(7); (T.shuffle if lib is nd else np.random.shuffle)(x); return x
+    t("shuffle 2d", lambda: shuf2(nd), lambda: shuf2(np))
+    # tensor_* helpers
+    t("tensor_shape", lambda: T.tensor_shape(d), lambda: a.shape)
+    t("tensor_size", lambda: T.tensor_size(d), lambda: a.size)
+    t("tensor_ndim", lambda: T.tensor_ndim(d), lambda: a.ndim)
+    t("tensor_dtype", lambda: T.tensor_dtype(d), lambda: a.dtype)
+    t("tensor_item", lambda: T.tensor_item(nd.asarray(np.float32(2.5))), lambda: np.float32(2.5).item())
+    t("tensor_item bad", lambda: T.tensor_item(d), lambda: a.item())
+    t("len", lambda: T.len(d), lambda: len(a))
+    t("len 0d", lambda: T.len(nd.asarray(np.float64(1))), lambda: len(np.float64(1)))
+    t("repr", lambda: T.repr(d).replace("DeviceArray(", "array(", 1), lambda: repr(a))
+    t("as_numpy", lambda: T.as_numpy(d), lambda: a)
+    t("array", lambda: T.array(d), lambda: np.array(a))
+    t("array dtype", lambda: T.array(d, dtype=np.float32), lambda: np.array(a, dtype=np.float32))
+    t("np.asarray", lambda: np.asarray(d), lambda: a)
+    t("np.array", lambda: np.array(d), lambda: a)
+    t("np.sum(device)", lambda: np.asarray(np.sum(d)), lambda: np.sum(a))
+    t("list()", lambda: [x.tolist() for x in d], lambda: [x.tolist() for x in a])
+    t("tolist", lambda: d.tolist(), lambda: a.tolist())
+    t("item", lambda: d[1,2].item(), lambda: a[1,2].item())
+    t("str", lambda: str(d), lambda: str(a))
+    t("format", lambda: format(d[0,1], ".2f"), lambda: format(a[0,1], ".2f"))
+    t("T attr", lambda: d.T, lambda: a.T)
+    t("nbytes", lambda: d.nbytes, lambda: a.nbytes)
+    t("itemsize", lambda: d.itemsize, lambda: a.itemsize)
+    t("flat-ish ravel", lambda: d.ravel(), lambda: a.ravel())
+    t("method sum axis kw", lambda: d.sum(1), lambda: a.sum(1))
+    t("method max", lambda: d.max(axis=0, keepdims=True), lambda: a.max(axis=0, keepdims=True))
+    t("method astype str", lambda: d.astype("int32"), lambda: a.astype("int32"))
+    t("method transpose args", lambda: d.transpose(1,0), lambda: a.transpose(1,0))
+    t("method transpose tuple", lambda: d.transpose((1,0)), lambda: a.transpose((1,0)))
+    t("method squeeze", lambda: d[:1].squeeze(), lambda: a[:1].squeeze())
+    t("method flatten", lambda: d.flatten(), lambda: a.flatten())
+    t("method clip", lambda: d.clip(2,7), lambda: a.clip(2,7))
+    t("method dot", lambda: d.dot(d.T), lambda: a.dot(a.T))
+    t("method repeat", lambda: d.repeat(2, axis=0), lambda: a.repeat(2, axis=0))
+    t("method nonzero", lambda: d.nonzero(), lambda: a.nonzero())
+    t("method argmin", lambda: d.argmin(axis=1), lambda: a.argmin(axis=1))
+    t("method fill", lambda: (lambda x: (x.fill(3), x)[1])(d.copy()), lambda: (lambda x: (x.fill(3), x)[1])(a.copy()))
+    t("method swapaxes", lambda: d.swapaxes(0,1), lambda: a.swapaxes(0,1))
+    t("method std", lambda: d.std(axis=0), lambda: a.std(axis=0))
+    t("method any", lambda: (d>5).any(axis=0), lambda: (a>5).any(axis=0))
+    t("method all", lambda: (d>5).all(), lambda: (a>5).all())
+    t("method prod", lambda: d.prod(axis=1), lambda: a.prod(axis=1))
+    t("method mean", lambda: d.mean(), lambda: a.mean())
+    t("size attr", lambda: d.size, lambda: a.size)
+    t("ndim attr", lambda: d.ndim, lambda: a.ndim)
+    t("shape attr", lambda: d.shape, lambda: a.shape)
+    t("hash", lambda: hash(d), lambda: hash(a))
+    t("iter 0d", lambda: list(nd.asarray(np.float64(1))), lambda: list(np.float64(1)))
+    t("int()", lambda: int(d[0,1]), lambda: int(a[0,1]))
+    t("int() many", lambda: int(d), lambda: int(a))
+    t("index()", lambda: [1,2,3][nd.asarray(np.int64(1))], lambda: [1,2,3][np.int64(1)])
+    t("index float", lambda: [1,2,3][d[0,1]], lambda: [1,2,3][a[0,1]])
+    t("complex()", lambda: complex(d[0,1]), lambda: complex(a[0,1]))
+    t("round()", lambda: round(d[0,1]), lambda: round(a[0,1]))
+    t("eq None", lambda: d == None, lambda: a == None)
+    t("eq str", lambda: d == "x", lambda: a == "x")
+    t("is in list", lambda: d in [d], lambda: True)
+    # save / load
+    def sl(lib, arr):
+        f = os.path.join(tempfile.mkdtemp(), "x.npy")
+        (T.save if lib is nd else np.save)(f, arr)
+        return (T.load if lib is nd else np.load)(f)
+    t("save/load", lambda: sl(nd, d), lambda: sl(np, a))
+    t("save/load T", lambda: sl(nd, d.T), lambda: sl(np, a.T))
+    t("load missing", lambda: T.load("/nonexistent/x.npy"), lambda: np.load("/nonexistent/x.npy"))
+    t.done()
+
+
 CASES = {"reductions_binaries": _reductions_and_binaries, "layout_creation_products": _layout_creation_products, "python_scalars": _python_scalars_into_arrays,
-         "indexing": _indexing, "promotion_matrix": _promotion_matrix}
+         "indexing": _indexing, "promotion_matrix": _promotion_matrix, "table_helpers_rng_methods": _table_helpers_rng_methods}
 
 
 @pytest.fixture
