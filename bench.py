@@ -549,7 +549,7 @@ def flat_keys(results):
                 kern("cfg4_bias_add", tail.get("add"), us=False)
                 kern("cfg4_where", tail.get("where"), us=False)
                 kern("cfg4_greater", tail.get("greater"), us=False)
-        elif name in ("cfg5", "cfg2", "cfg2_weak", "cfg4_strong"):
+        elif name in ("cfg5", "cfg5_graph", "cfg2", "cfg2_weak", "cfg4_strong"):
             put(name + "_frac", roof.get("frac"))
             if roof.get("avg_launch_ms") is not None:
                 put(name + "_gemm_us", roof["avg_launch_ms"] * 1e3)
@@ -562,8 +562,11 @@ def flat_keys(results):
     return f
 
 
+# sweeps per secondary config: ~40 ms of timed region each (ms per sweep: 1.7 / 0.4 / 3.9 / 3.7 / 0.65 / 0.63)
+SECONDARY_STEPS = {"cfg3": 24, "cfg3_lazy": 100, "cfg4": 10, "cfg4_lazy": 10, "cfg5": 60, "cfg5_graph": 60}
+
 # keys of `roofline` given up first when the line would pass 2 KB (everything stays in bench_detail.json)
-DROP_ORDER = ["cfg4_greater_frac", "cfg4_where_frac", "cfg3_cos_frac", "cfg3_loss_sum_frac", "traffic_committed_source", "min_launch_ms",
+DROP_ORDER = ["cfg5_graph_gemm_us", "cfg5_graph_frac", "cfg4_greater_frac", "cfg4_where_frac", "cfg3_cos_frac", "cfg3_loss_sum_frac", "traffic_committed_source", "min_launch_ms",
               "cfg3_lazy_loss_pass_frac", "cfg3_lazy_grad_pass_frac", "cfg4_lazy_gemm_frac", "cfg4_bias_add_frac", "cfg3_mul_bytes",
               "cfg4_lazy_pair_bytes", "launches", "median_launch_ms", "cfg3_sin_us", "cfg4_maskprod_us", "cfg4_colsum_us"]
 
@@ -997,6 +1000,11 @@ def main(entry=None):
             plan = [(f"{wl}{'_lazy' if lz else ''}", wl, lz) for wl in ("cfg3", "cfg4", "cfg5", "cfg2") for lz in (False, True)
                     if not (wl in ("cfg5", "cfg2") and lz)]
             plan = [p for p in plan if not (p[1] == args.workload and p[2] == bool(args.lazy))]
+            # cfg5's sweep is eleven short launches (five 124-us GEMMs, fills, sums): the same sweep replayed from ONE captured
+            # hipGraph (graph.CapturedSweep, the mode SweepCache serves reuse_graph() with) — what the launch boundaries cost
+            from minidiff_amd.graph import can_capture
+            if args.workload != "cfg5" and can_capture(lib):      # (the CPU test double cannot replay)
+                plan.insert(plan.index(("cfg5", "cfg5", False)) + 1, ("cfg5_graph", "cfg5", "graph"))
         keep, keep_wl = None, None
         for name, wl, lz in plan:
             if wl != keep_wl:
@@ -1004,7 +1012,15 @@ def main(entry=None):
                 gc.collect()
                 lib.empty_cache()
             try:
-                r = run(wl, lz, k_sec, w_sec, size=args.size, keep=keep, want_grads=check_grads)
+                # a timed region of >= ~40 ms for the short sweeps too (ten sweeps of cfg3 --lazy are 4 ms: the first ones after
+                # the workload switch weighed 5-7 %); explicit small --steps (tests) are kept
+                k_this = k_sec
+                if args.steps >= 10 and not args.size:
+                    k_this = max(k_sec, SECONDARY_STEPS.get(name, k_sec))
+                if lz == "graph":
+                    r = run(wl, False, k_this, w_sec, graph=True, size=args.size, keep=None)
+                else:
+                    r = run(wl, lz, k_this, w_sec, size=args.size, keep=keep, want_grads=check_grads)
                 if use_dist:    # its own single-GPU figure, same job
                     keep.clear()
                     r["single_gpu_same_workload"] = solo_run(wl, lz)

@@ -429,7 +429,6 @@ struct HipExec {
   template <class F, class Tc, class To>
   static int unary(const MdIter &it, const mdhip_array *x, const mdhip_array *out) {
     using Tx = typename md_storage<Tc>::type;
-    hipStream_t st = md_stream();
     Tc sx = x->is_scalar ? md_scalar_as<Tc>(x) : Tc();
     FastGeom g;
     FastOp<Tx> fx;
@@ -464,10 +463,10 @@ struct HipExec {
     int64_t B, R, Cn, xb, xc;
     if (!x->is_scalar && it.total >= (1 << 14) && tr_geom(it, 0, 1, &B, &R, &Cn, &xb, &xc)) {
       const int tr = (int)((R + 63) / 64), tc = (int)((Cn + 63) / 64);
-      k_unary_tr<F, Tc, To><<<(unsigned)(B * tr * tc), MD_BLOCK, 0, st>>>(x->data, x->dtype, xb, xc, (To *)out->data, R, Cn, tr, tc);
+      MD_LAUNCH((k_unary_tr<F, Tc, To>), (unsigned)(B * tr * tc), MD_BLOCK, x->data, x->dtype, xb, xc, (To *)out->data, R, Cn, tr, tc);
       return MD_LAUNCH_CHECK("unary(transposed)");
     }
-    k_unary_generic<F, Tc, To><<<md_grid_for(it.total), MD_BLOCK, 0, st>>>(it, x->data, x->dtype, x->is_scalar, sx, (To *)out->data);
+    MD_LAUNCH((k_unary_generic<F, Tc, To>), md_grid_for(it.total), MD_BLOCK, it, x->data, x->dtype, x->is_scalar, sx, (To *)out->data);
     return MD_LAUNCH_CHECK("unary(generic)");
   }
 
@@ -512,8 +511,10 @@ struct HipExec {
         if (try_binary_fast<F, Tc, To, b8, Ts>(it, g, a, b, out, sa, sb, &status)) return status;
       }
     }
-    k_binary_generic<F, Tc, To><<<md_grid_for(it.total), MD_BLOCK, 0, md_stream()>>>(
-        it, a->data, a->dtype, a->is_scalar, sa, b->data, b->dtype, b->is_scalar, sb, (To *)out->data);
+    // (MD_LAUNCH everywhere a call's main kernel starts: bench.py's attached events then time THAT kernel; a path that ignored them
+    // sent the whole tag to marker brackets, ~5 us long on a 30-us kernel)
+    MD_LAUNCH((k_binary_generic<F, Tc, To>), md_grid_for(it.total), MD_BLOCK, it, a->data, a->dtype, a->is_scalar, sa, b->data, b->dtype, b->is_scalar, sb,
+              (To *)out->data);
     return MD_LAUNCH_CHECK("binary(generic)");
   }
 
@@ -543,9 +544,8 @@ struct HipExec {
       using Body = WhereBody<T, b8, OM_FLEX, OM_FLEX, OM_FLEX>;
       return launch_fast<Body, 1>(Body{fc, fa, fb, sc, sa, sb, o}, g, "where(fast,flex)");
     }
-    k_where_generic<T><<<md_grid_for(it.total), MD_BLOCK, 0, md_stream()>>>(
-        it, c->data, c->dtype, c->is_scalar, sc, a->data, a->dtype, a->is_scalar, sa, b->data, b->dtype, b->is_scalar, sb,
-        (T *)out->data);
+    MD_LAUNCH((k_where_generic<T>), md_grid_for(it.total), MD_BLOCK, it, c->data, c->dtype, c->is_scalar, sc, a->data, a->dtype, a->is_scalar, sa, b->data,
+              b->dtype, b->is_scalar, sb, (T *)out->data);
     return MD_LAUNCH_CHECK("where(generic)");
   }
 };
