@@ -9,7 +9,7 @@ import sys
 
 import numpy as np
 
-os.environ.setdefault("MDHIP_EXPERIMENTS", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from minidiff_amd import _capi, ndarray as nd  # noqa: E402
 
