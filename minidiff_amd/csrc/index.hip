@@ -541,6 +541,96 @@ static int scatter_runs(const mdhip_index_plan *pl, int64_t P, int64_t L, void *
   return rc;
 }
 
+// ---- element-granular order: sort the positions by destination, one serial pass per destination -----------------------
+// np.add.at with duplicate destinations at ELEMENT granularity (a histogram: a million contributions into ten bins) and a[idx] = v
+// with repeats. The positions' destination offsets are sorted stably (plan order survives among equal destinations), then the
+// thread that holds the FIRST position of a destination applies that destination's contributions one after the other — NumPy's
+// order, O(n log n) whatever the multiplicities, no host round trip (capturable). The bid / apply rounds below (one round, one
+// host read-back, per multiplicity level: a million rounds for a million contributions to one element) remain only for plans
+// beyond the sort's 2^27 positions.
+__global__ void __launch_bounds__(MD_BLOCK) k_elem_offsets(mdhip_index_plan pl, int64_t total, int64_t lo, uint64_t *keys, int64_t *ids) {
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
+    int64_t pos[MDHIP_MAX_NDIM];
+    bool oob = false;
+    keys[i] = (uint64_t)(md_plan_offset(pl, i, pos, &oob) - lo);
+    ids[i] = i;
+  }
+}
+template <class T, int MODE>
+__global__ void __launch_bounds__(MD_BLOCK) k_elem_apply(mdhip_index_plan pl, int64_t total, int64_t lo, const uint64_t *__restrict__ keys,
+                                                        const int64_t *__restrict__ ids, T *dst, ValDesc v, T s) {
+  MD_SCATTER_GUARD(v);
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= total) return;
+  const uint64_t key = keys[q];
+  if (q > 0 && keys[q - 1] == key) return;   // not the first contribution of its destination
+  T *d = dst + ((int64_t)key + lo);
+  auto value = [&](int64_t p) -> T {
+    if (v.is_scalar) return s;
+    int64_t lin = p, vo = 0;
+    for (int dd = pl.ndim - 1; dd >= 0; --dd) {
+      const int64_t e = pl.shape[dd], qq = lin / e;
+      vo += (lin - qq * e) * v.strides[dd];
+      lin = qq;
+    }
+    return ((const T *)v.p)[vo];
+  };
+  if constexpr (MODE == MDHIP_SCATTER_ADD) {
+    T acc = *d;
+    for (int64_t q2 = q; q2 < total && keys[q2] == key; ++q2) {
+      if constexpr (md_same<T, uint8_t>::value) acc = (uint8_t)(acc || value(ids[q2]));
+      else acc = md_storage_add(acc, value(ids[q2]));
+    }
+    *d = acc;
+  } else {
+    int64_t q2 = q;
+    while (q2 + 1 < total && keys[q2 + 1] == key) ++q2;
+    *d = value(ids[q2]);
+  }
+}
+// every destination offset of the plan lies in [lo, hi] (host side, from the extents)
+static void plan_offset_range(const mdhip_index_plan *pl, int64_t *lo_out, int64_t *hi_out) {
+  int64_t lo = 0, hi = 0;
+  for (int d = 0; d < pl->ndim; ++d) {
+    const int64_t e = (pl->shape[d] - 1) * pl->src_strides[d];
+    if (e < 0) lo += e; else hi += e;
+  }
+  for (int k = 0; k < pl->n_idx; ++k) {
+    const int64_t e = (pl->idx_extent[k] - 1) * pl->idx_mult[k];
+    if (e < 0) lo += e; else hi += e;
+  }
+  *lo_out = lo;
+  *hi_out = hi;
+}
+template <class T, int MODE>
+static int scatter_ordered(const mdhip_index_plan *pl, int64_t total, void *dst, const ValDesc &v, T s);
+template <class T, int MODE>
+static int scatter_sorted(const mdhip_index_plan *pl, int64_t total, void *dst, const ValDesc &v, T s) {
+  if (total >= (1ll << 27)) return scatter_ordered<T, MODE>(pl, total, dst, v, s);   // (the sort keeps 256 counters per 2048 positions)
+  hipStream_t st = md_stream();
+  int64_t lo, hi;
+  plan_offset_range(pl, &lo, &hi);
+  int key_bits = 1;
+  while (key_bits < 64 && ((uint64_t)(hi - lo) >> key_bits) != 0) ++key_bits;
+  void *keys = nullptr, *ids = nullptr;
+  MD_TRY(mdhip_alloc((size_t)total * 16, &keys));
+  int rc = mdhip_alloc((size_t)total * 16, &ids);
+  if (rc == MDHIP_OK) {
+    k_elem_offsets<<<md_grid_for(total), MD_BLOCK, 0, st>>>(*pl, total, lo, (uint64_t *)keys, (int64_t *)ids);
+    int half = 0;
+    rc = radix_sort_pairs((uint64_t *)keys, (int64_t *)ids, total, key_bits, &half);
+    if (rc == MDHIP_OK) {
+      const int64_t blocks = (total + MD_BLOCK - 1) / MD_BLOCK;   // (< 2^19: one position per thread)
+      k_elem_apply<T, MODE><<<(unsigned)blocks, MD_BLOCK, 0, st>>>(*pl, total, lo, (const uint64_t *)keys + half * total, (const int64_t *)ids + half * total, (T *)dst, v, s);
+      rc = MD_LAUNCH_CHECK("scatter(sorted)");
+    }
+  }
+  if (ids) mdhip_free(ids);
+  mdhip_free(keys);
+  return rc;
+}
+
 // order-preserving rounds (see k_bid / k_apply)
 template <class T, int MODE>
 static int scatter_ordered(const mdhip_index_plan *pl, int64_t total, void *dst, const ValDesc &v, T s) {
@@ -589,24 +679,23 @@ static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, c
     return MD_LAUNCH_CHECK("scatter(serial)");
   }
   if constexpr (SMALL) {
-    if (mode == MDHIP_SCATTER_SET) return scatter_ordered<T, MDHIP_SCATTER_SET>(pl, total, dst, v, s);
-    return scatter_ordered<T, MDHIP_SCATTER_ADD>(pl, total, dst, v, s);
+    if (mode == MDHIP_SCATTER_SET) return scatter_sorted<T, MDHIP_SCATTER_SET>(pl, total, dst, v, s);
+    return scatter_sorted<T, MDHIP_SCATTER_ADD>(pl, total, dst, v, s);
   } else {
   int64_t L = 0, P = 0;
   const bool runs = run_geometry(pl, &L, &P);
   if (mode == MDHIP_SCATTER_SET) {
     if (runs) return scatter_runs<T, MDHIP_SCATTER_SET>(pl, P, L, dst, v, s, unique_rows);
-    return scatter_ordered<T, MDHIP_SCATTER_SET>(pl, total, dst, v, s);
+    return scatter_sorted<T, MDHIP_SCATTER_SET>(pl, total, dst, v, s);
   }
   if constexpr (md_same<T, uint8_t>::value) {
-    k_scatter_serial<T, MDHIP_SCATTER_ADD><<<1, 64, 0, st>>>(*pl, total, (T *)dst, v, s);
-    return MD_LAUNCH_CHECK("scatter(add,bool)");
+    return scatter_sorted<T, MDHIP_SCATTER_ADD>(pl, total, dst, v, s);   // (bool: logical or per destination)
   } else if constexpr (!is_fp) {
     k_scatter_add_int<T><<<md_grid_for(total), MD_BLOCK, 0, st>>>(*pl, total, (T *)dst, v, s);
     return MD_LAUNCH_CHECK("scatter(add,int)");
   } else {
     if (runs) return scatter_runs<T, MDHIP_SCATTER_ADD>(pl, P, L, dst, v, s, unique_rows);
-    return scatter_ordered<T, MDHIP_SCATTER_ADD>(pl, total, dst, v, s);
+    return scatter_sorted<T, MDHIP_SCATTER_ADD>(pl, total, dst, v, s);
   }
   }
 }
@@ -768,7 +857,9 @@ int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const m
     case 2: k_gather<uint16_t><<<grid, MD_BLOCK, 0, st>>>(*pl, total, (const uint16_t *)src, (uint16_t *)out->data, oit, (int *)flag); break;
     case 4: k_gather<uint32_t><<<grid, MD_BLOCK, 0, st>>>(*pl, total, (const uint32_t *)src, (uint32_t *)out->data, oit, (int *)flag); break;
     case 8: k_gather<uint64_t><<<grid, MD_BLOCK, 0, st>>>(*pl, total, (const uint64_t *)src, (uint64_t *)out->data, oit, (int *)flag); break;
-    default: if (!captured) mdhip_free(flag); return md_fail(MDHIP_ETYPE, "gather: bad dtype code %d", dtype);
+    default:
+      if (!captured) mdhip_free(flag);
+      return md_fail(MDHIP_ETYPE, "gather: bad dtype code %d", dtype);
   }
   int rc = MD_LAUNCH_CHECK("gather");
   if (captured) return rc;

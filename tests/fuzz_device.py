@@ -399,6 +399,8 @@ def main(n=2000, seed=0, big=False, narrow=False):
                 traceback.print_exc()
         if fails >= 25:
             break
+        if (i + 1) % 500 == 0:
+            print(f"  .. {i + 1} cases, {fails} failures", flush=True)     # (a long run must keep writing: a silent GPU job is taken for hung)
     print(f"fuzz: {n} cases, seed {seed}, big={big}, narrow={narrow}: {fails} failures", flush=True)
     return fails
 

@@ -321,6 +321,9 @@ def test_captured_gather_scatter_defer_their_bounds_verdict(lib, on_gpu):
     t, r, f, c = nd.asarray(table), nd.asarray(rows), nd.asarray(few), nd.asarray(cols)
     acc, acc_i, small = nd.zeros((512, 64), np.float32), nd.zeros((512, 64), np.int64), nd.zeros((512, 64), np.float32)
     upd = nd.asarray(np.ones((6000, 64), np.float32))
+    bins = rng.integers(0, 10, 6000)                      # element granularity, ~600 contributions per destination: the sorted path
+    binv = rng.standard_normal(6000).astype(np.float32)
+    hist, b_, bv_ = nd.zeros((16,), np.float32), nd.asarray(bins), nd.asarray(binv)
     outs = {}
 
     def body():
@@ -330,6 +333,7 @@ def test_captured_gather_scatter_defer_their_bounds_verdict(lib, on_gpu):
         nd.index_add(acc, r, upd)                         # float rows, duplicates: sort + apply
         nd.index_add(acc_i, r, 1)                         # integer: atomics
         small[f] = 2.0                                    # serial SET
+        nd.index_add(hist, b_, bv_)                       # sort by destination + one serial pass each (no host rounds)
 
     nd._lib().sync()
     h = C.c_void_p()
@@ -347,6 +351,8 @@ def test_captured_gather_scatter_defer_their_bounds_verdict(lib, on_gpu):
         assert np.array_equal(acc.get(), e_acc) and np.array_equal(acc_i.get(), e_acc.astype(np.int64))
         e_small = np.zeros((512, 64), np.float32); e_small[few] = 2.0
         assert np.array_equal(small.get(), e_small)
+        e_hist = np.zeros(16, np.float32); np.add.at(e_hist, bins, binv)
+        assert np.array_equal(hist.get(), e_hist)
         # bad row index in the scatter-add's plan: the replay raises at the synchronisation and the scatters wrote nothing
         rows_bad = rows.copy(); rows_bad[4321] = 512
         r[...] = nd.asarray(rows_bad)

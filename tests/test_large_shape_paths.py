@@ -411,3 +411,54 @@ def test_f64_tn_direct_to_lds_gpu(lib, on_gpu, mdopt):
         assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-14
     finally:
         mdopt("gemm_glds", 1)
+
+
+def _heavy_duplicates(nd, n):
+    """np.add.at / a[idx] = v with MANY positions per destination at element granularity (a histogram): positions sorted by
+    destination, one serial pass per destination (csrc/index.hip scatter_sorted) — NumPy's accumulation order bit for bit, and no
+    round trip per multiplicity level (a million contributions to one element used to be a million host-driven rounds)."""
+    import time
+    rng = np.random.default_rng(8)
+    for dt in (np.float32, np.float64, np.float16, np.int8, np.int16, np.uint8, np.bool_, np.int32):
+        kind = np.dtype(dt).kind
+        bins = rng.integers(0, 10, n)                               # ten destinations
+        vals = (rng.standard_normal(n) * 3).astype(dt) if kind == "f" else (rng.integers(0, 2, n).astype(dt) if kind == "b" else rng.integers(-5, 6, n).astype(dt))
+        a = np.zeros(16, dt)
+        d = nd.asarray(a)
+        t0 = time.perf_counter()
+        nd.index_add(d, nd.asarray(bins), nd.asarray(vals))
+        got = d.get()
+        dt_s = time.perf_counter() - t0
+        with np.errstate(all="ignore"):
+            np.add.at(a, bins, vals)
+        assert np.array_equal(got, a, equal_nan=(kind == "f")), (dt, got, a)
+        assert dt_s < 20.0, (dt, dt_s)
+        # last write wins, in plan order
+        a2 = np.zeros(16, dt); d2 = nd.asarray(a2)
+        d2[nd.asarray(bins)] = nd.asarray(vals); a2[bins] = vals
+        assert np.array_equal(d2.get(), a2, equal_nan=(kind == "f")), dt
+    # two index arrays, strided destination, scalar value; every position on ONE element
+    a = np.zeros((7, 9), np.float32); d = nd.asarray(a)
+    i0, i1 = rng.integers(0, 7, n), rng.integers(0, 9, n)
+    nd.index_add(d[::-1, ::2], (nd.asarray(i0 % 7), nd.asarray(i1 % 5)), np.float32(0.1))
+    np.add.at(a[::-1, ::2], (i0 % 7, i1 % 5), np.float32(0.1))
+    assert np.array_equal(d.get(), a)
+    one = np.zeros(3, np.float32); done = nd.asarray(one)
+    v = rng.standard_normal(n).astype(np.float32)
+    nd.index_add(done, nd.asarray(np.full(n, 1)), nd.asarray(v))
+    np.add.at(one, np.full(n, 1), v)
+    assert np.array_equal(done.get(), one)
+
+
+def test_heavy_duplicate_scatters_cpu(lib, on_gpu):
+    if on_gpu:
+        pytest.skip("other twin")
+    from minidiff_amd import ndarray as nd
+    _heavy_duplicates(nd, 20000)
+
+
+@pytest.mark.gpu
+def test_heavy_duplicate_scatters_gpu(lib, on_gpu):
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    _heavy_duplicates(nd, 300000)
