@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(MD_BLOCK) k_run_apply(mdhip_index_plan pl, int
     };
     if constexpr (MODE == MDHIP_SCATTER_ADD) {
       T acc = *d;
-      for (int64_t q2 = q; q2 < P && keys[q2] == key; ++q2) acc = BAdd::apply(acc, value(ids[q2]));
+      for (int64_t q2 = q; q2 < P && keys[q2] == key; ++q2) acc = md_storage_add(acc, value(ids[q2]));
       *d = acc;
     } else {
       int64_t q2 = q;
@@ -503,7 +503,7 @@ static void run_key_range(const mdhip_index_plan *pl, int64_t L, int64_t *lo_out
 }
 
 // `unique`: the census of the bounds pass found no destination row twice — plan order is irrelevant, no sort
-template <class T, int MODE>
+template <class T, int MODE, bool VEC_OK = true>
 static int scatter_runs(const mdhip_index_plan *pl, int64_t P, int64_t L, void *dst, const ValDesc &v, T s, bool unique) {
   hipStream_t st = md_stream();
   // keys are offset - lo, so the sort needs bits(hi - lo) only
@@ -529,10 +529,12 @@ static int scatter_runs(const mdhip_index_plan *pl, int64_t P, int64_t L, void *
       // duplicates the busy items are few and clustered — under a capped grid a trip held 4 of 64 busy rows (16 blocks at work,
       // 16 trips one after the other: 0.9 TB/s); every other block exits at once
       auto full_grid = [](int64_t items) { const int64_t b = (items + MD_BLOCK - 1) / MD_BLOCK; return (unsigned)(b < 1 ? 1 : (b > 0x7fffffffll ? 0x7fffffffll : b)); };
-      if (run_vectorisable<T>(pl, L, dst, v))
-        k_run_apply_vec<T, MODE><<<full_grid(P * (L / (16 / (int64_t)sizeof(T)))), MD_BLOCK, 0, st>>>(*pl, P, L, lo, unit, kout, iout, (T *)dst, v, s);
-      else
-        k_run_apply<T, MODE><<<full_grid(P * L), MD_BLOCK, 0, st>>>(*pl, P, L, lo, unit, kout, iout, (T *)dst, v, s);
+      bool vec = false;
+      if constexpr (VEC_OK) vec = run_vectorisable<T>(pl, L, dst, v);
+      if constexpr (VEC_OK) {
+        if (vec) k_run_apply_vec<T, MODE><<<full_grid(P * (L / (16 / (int64_t)sizeof(T)))), MD_BLOCK, 0, st>>>(*pl, P, L, lo, unit, kout, iout, (T *)dst, v, s);
+      }
+      if (!vec) k_run_apply<T, MODE><<<full_grid(P * L), MD_BLOCK, 0, st>>>(*pl, P, L, lo, unit, kout, iout, (T *)dst, v, s);
       rc = MD_LAUNCH_CHECK("scatter(runs)");
     }
   }
@@ -679,6 +681,12 @@ static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, c
     return MD_LAUNCH_CHECK("scatter(serial)");
   }
   if constexpr (SMALL) {
+    // whole rows (the last axis a contiguous run no index varies along): order at ROW granularity, as for the wide types
+    int64_t Ls = 0, Ps = 0;
+    if (run_geometry(pl, &Ls, &Ps)) {
+      if (mode == MDHIP_SCATTER_SET) return scatter_runs<T, MDHIP_SCATTER_SET, false>(pl, Ps, Ls, dst, v, s, false);
+      return scatter_runs<T, MDHIP_SCATTER_ADD, false>(pl, Ps, Ls, dst, v, s, false);
+    }
     if (mode == MDHIP_SCATTER_SET) return scatter_sorted<T, MDHIP_SCATTER_SET>(pl, total, dst, v, s);
     return scatter_sorted<T, MDHIP_SCATTER_ADD>(pl, total, dst, v, s);
   } else {

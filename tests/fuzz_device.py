@@ -241,6 +241,8 @@ def one_case(rng, big):
             d = nd.asarray(h)
             ax = int(rng.integers(0, h.ndim))
             n = int(rng.integers(1, 12 if not big else 3000))
+            # (a value of at most 2e7 elements: 2608 repeats of a 2-million-element slab once drew 5.6e9 positions — 7.5 minutes in NumPy alone)
+            n = min(n, max(1, 20_000_000 // max(h.size // h.shape[ax], 1)))
             idx = rng.integers(-h.shape[ax], h.shape[ax], (n,))
             vshape = h.shape[:ax] + (n,) + h.shape[ax + 1:]
             vals = rand_array(rng, vshape, h.dtype)

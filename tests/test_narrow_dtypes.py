@@ -252,14 +252,16 @@ def _index_and_compare(nd):
     rng = np.random.default_rng(77)
     for dt in NARROW:
         kind = np.dtype(dt).kind
-        for n, m in ((40, 25), (3000, 9000)):
+        # (three columns: element-granular order — serial below 4096 positions, sorted by destination above; sixteen columns: whole
+        # rows, ordered at row granularity)
+        for n, m, w in ((40, 25, 3), (3000, 9000, 3), (300, 6000, 16)):
             if kind == "f":
-                a = (rng.standard_normal((n, 3)) * 8).astype(dt)
-                v = (rng.standard_normal((m, 3)) * 8).astype(dt)
+                a = (rng.standard_normal((n, w)) * 8).astype(dt)
+                v = (rng.standard_normal((m, w)) * 8).astype(dt)
             else:
                 info = np.iinfo(dt)
-                a = rng.integers(info.min, info.max, (n, 3), dtype=dt, endpoint=True)      # the whole range: uint64 >= 2**63 included
-                v = rng.integers(info.min, info.max, (m, 3), dtype=dt, endpoint=True)
+                a = rng.integers(info.min, info.max, (n, w), dtype=dt, endpoint=True)      # the whole range: uint64 >= 2**63 included
+                v = rng.integers(info.min, info.max, (m, w), dtype=dt, endpoint=True)
             idx = rng.integers(-n, n, m)                                                    # duplicates, negative indices
             da, dv, di = nd.asarray(a), nd.asarray(v), nd.asarray(idx)
             assert np.array_equal(da[di].get(), a[idx]), (dt, n, "getitem")
@@ -277,10 +279,10 @@ def _index_and_compare(nd):
                 # (a typed scalar: for a bare Python int against uint64, NumPy's ufunc.at detours through float64 and drops low bits)
                 nd.index_add(c, di, dt(3)); np.add.at(r, idx, dt(3))
             assert np.array_equal(c.get(), r, equal_nan=(kind == "f")), (dt, n, "index_add scalar")
-            ai = rng.integers(0, n, (n, 3))
+            ai = rng.integers(0, n, (n, w))
             assert np.array_equal(nd.take_along_axis(da, nd.asarray(ai), 0).get(), np.take_along_axis(a, ai, 0)), (dt, n, "take_along_axis")
             c, r = da.copy(), a.copy()
-            pi = np.argsort(rng.random((n, 3)), axis=0)[: n // 2]
+            pi = np.argsort(rng.random((n, w)), axis=0)[: n // 2]
             nd.put_along_axis(c, nd.asarray(pi), dv[: n // 2], 0); np.put_along_axis(r, pi, v[: n // 2], 0)
             assert np.array_equal(c.get(), r), (dt, n, "put_along_axis")
         if kind in "iu":
