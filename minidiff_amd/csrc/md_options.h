@@ -47,7 +47,8 @@
   X(ROWS_BLOCKS, "rows_blocks", 0, 'x')                /* blocks of a split row reduction (0: 1024) */                          \
   X(ARG_BLOCKS, "arg_blocks", 0, 'x')                  /* blocks of the strips arg-reduction (0: one per CU) */                 \
   X(GATHER_RUNS, "gather_runs", 1, 'x')                                                                                         \
-  X(SCATTER_CENSUS, "scatter_census", 1, 'x')
+  X(SCATTER_CENSUS, "scatter_census", 1, 'x')                                                                                   \
+  X(SCATTER_SORTED, "scatter_sorted", 1, 'x')          /* 0: element-granular duplicates by bid / apply rounds (A/B) */
 
 enum MdOptId {
 #define MD_OPT_ENUM(ID, name, dflt, kind) MD_OPT_##ID,
