@@ -2051,15 +2051,17 @@ def _as3d(x: DeviceArray, batch_shape: tuple):
 
 
 def matmul(a, b, out=None, **kw):
-    _defaults_only("matmul", kw)
     """np.matmul (numpy.py:84). `out`: like NumPy's — a C-contiguous array of the result's shape and dtype that
     receives the product (dp.GradSync points it at a row panel of the all-reduce bucket)."""
+    _defaults_only("matmul", kw)
     a, b = asarray(a), asarray(b)
     if a.ndim == 0 or b.ndim == 0:
         raise ValueError("matmul: Input operand does not have enough dimensions (has 0, gufunc core with signature (n?,k),(k,m?)->(n?,m?) requires 1)")
     odt = np.result_type(a.dtype, b.dtype)
     if odt == np.bool_:
-        raise TypeError("matmul on bool operands is not supported by the MI355X backend")
+        # NumPy's boolean loop: "any k with a[i, k] and b[k, j]" — the integer product of the 0 / 1 operands is the count of such k
+        res = greater(matmul(astype(a, np.int32), astype(b, np.int32)), 0)
+        return _finish_out(res, out, "matmul")
     dtype_code(odt)
     if a.dtype != odt:
         a = astype(a, odt)

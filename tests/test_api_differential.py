@@ -179,6 +179,10 @@ def _layout_creation_products(nd):
                               (nd.asarray(ai[0]), nd.asarray(m.T[:5]), ai[0], m.T[:5], "int@float")):
         t(f"matmul {nm}", lambda: nd.matmul(x, y), lambda: np.matmul(nx, ny))
         t(f"dot {nm}", lambda: nd.dot(x, y), lambda: np.dot(nx, ny))
+    bm, bn = rng.random((5, 7)) > 0.7, rng.random((7, 3)) > 0.7      # boolean products: "any k with a[i, k] and b[k, j]"
+    for x, y in ((bm, bn), (bm[0], bn), (bm, bn[:, 0]), (bm[0], bn[:, 0]), (np.stack([bm, bm]), bn)):
+        t(f"matmul bool {x.shape}{y.shape}", lambda: nd.matmul(nd.asarray(x), nd.asarray(y)), lambda: np.matmul(x, y))
+        t(f"dot bool {x.shape}{y.shape}", lambda: nd.dot(nd.asarray(x), nd.asarray(y)), lambda: np.dot(x, y))
     at = np.ascontiguousarray(a.transpose(2, 1, 0)); dat = nd.asarray(at)
     for axes in (0, 1, 2, ([1], [0]), ([2], [1]), ((0, 1), (0, 1)), ([0, 1], [1, 0]), 3, ([0], [0, 1])):
         t(f"tensordot {axes}", lambda: nd.tensordot(d, dat, axes=axes), lambda: np.tensordot(a, at, axes=axes))
