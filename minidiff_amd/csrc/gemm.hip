@@ -1687,6 +1687,11 @@ static int launch_f64_pick(const GemmArgs64 &ga, int64_t batch, bool edge) {
 struct HipExec {
   template <class T> static int gemm(const MdGemm &g_in) {
     if (g_in.batch > 65535) return md_fail(MDHIP_EVALUE, "matmul: batch extent %lld exceeds 65535", (long long)g_in.batch);
+    if constexpr (md_same<T, float>::value || md_same<T, double>::value || md_same<T, int32_t>::value || md_same<T, int64_t>::value) {
+      // both sides thin and k long (np.dot of two vectors): k cut over the chip, fixed-order sum of the block partials (skinny.hip)
+      const int rc = md_gemm_longk(g_in, md_dtype_of<T>::value);
+      if (rc >= 0) return rc;
+    }
     if constexpr (md_same<T, float>::value || md_same<T, double>::value) {
       // a thin side (matrix x vector, a few columns / rows): HBM-bound streaming kernels (skinny.hip)
       const int rc = md_gemm_skinny(g_in, md_same<T, float>::value ? MDHIP_F32 : MDHIP_F64);

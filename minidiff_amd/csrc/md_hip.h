@@ -11,6 +11,7 @@
 hipStream_t md_stream();
 struct MdGemm;
 int md_gemm_skinny(const MdGemm &g, int dtype);           // skinny.hip: thin products (matrix x vector ..); -1 = not applicable
+int md_gemm_longk(const MdGemm &g, int dtype);            // skinny.hip: both sides thin, k long (a dot product ..); -1 = not applicable
 unsigned *md_tickets();                                   // MD_TICKET_WORDS zeroed counters (md_ticket.h)
 bool md_capturing();                                      // a stream capture is recording (mdhip_graph_begin .. _end)
 int *md_sticky();                                         // host-mapped word a CAPTURED gather / scatter sets on an out-of-bounds index

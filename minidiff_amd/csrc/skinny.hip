@@ -340,6 +340,136 @@ template <class T> int skinny_run(const SkinnyArgs &a, int64_t batch, bool rowdo
 
 }  // namespace
 
+// ---- few outputs, k long: a dot product, (1,K)@(K,1), a few rows times a few columns, (64,K)@(K,64) ----------------------------
+// A product with at most a few thousand outputs and k in the millions gives a tile kernel ONE block (or a handful) that walks k
+// alone: 27-80 ns per k — a 4-million-element np.dot took 115 ms, (16, 2^20) @ (2^20, 16) 39 ms. Here k is cut over up to ~2048
+// blocks: a block owns an (up to) 8 x 8 patch of the output and a k range, a thread strides that range and keeps the patch's
+// partial sums, the block folds them (wave shuffles, then LDS), and a second small launch adds the block partials in block order —
+// fixed order, bit-identical run to run. float32 / float64 / int32 / int64 (integers wrap as NumPy's).
+namespace {
+struct LongKArgs {
+  const void *A, *B;
+  void *C, *partial;
+  int64_t K, chunk;
+  int64_t a_bs, a_ms, a_ks, b_bs, b_ks, b_ns, c_bs, c_ms, c_ns;
+  int M, N, nb, tiles_m, tiles_n;
+};
+template <class T> __device__ __forceinline__ T longk_mac(T acc, T x, T y) {
+  if constexpr (md_is_float<T>::value) return x * y + acc;   // (contracted to an fma)
+  else return BAdd::apply(acc, BMul::apply(x, y));            // integers wrap, as NumPy's
+}
+template <class T, int TM, int TN>
+__global__ void __launch_bounds__(MD_BLOCK) k_longk_partial(LongKArgs g) {
+  __shared__ T red[MD_BLOCK / 64][TM * TN];
+  const int tiles = g.tiles_m * g.tiles_n, bz = blockIdx.y / tiles, tile = blockIdx.y - bz * tiles;
+  const int m0 = (tile / g.tiles_n) * TM, n0 = (tile % g.tiles_n) * TN;
+  const T *A = (const T *)g.A + (int64_t)bz * g.a_bs + (int64_t)m0 * g.a_ms;
+  const T *B = (const T *)g.B + (int64_t)bz * g.b_bs + (int64_t)n0 * g.b_ns;
+  const int mm = g.M - m0, nn = g.N - n0;   // live rows / columns of this patch
+  const int64_t k0 = (int64_t)blockIdx.x * g.chunk, k1 = k0 + g.chunk < g.K ? k0 + g.chunk : g.K;
+  T acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) acc[m][n] = T(0);
+  for (int64_t k = k0 + threadIdx.x; k < k1; k += MD_BLOCK) {
+    T a[TM], b[TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) a[m] = m < mm ? A[m * g.a_ms + k * g.a_ks] : T(0);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) b[n] = n < nn ? B[k * g.b_ks + n * g.b_ns] : T(0);
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int n = 0; n < TN; ++n) acc[m][n] = longk_mac<T>(acc[m][n], a[m], b[n]);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      T v = acc[m][n];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) v = BAdd::apply(v, (T)__shfl_down(v, d, 64));
+      if (lane == 0) red[w][m * TN + n] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < TM * TN) {
+    T v = red[0][threadIdx.x];
+#pragma unroll
+    for (int ww = 1; ww < MD_BLOCK / 64; ++ww) v = BAdd::apply(v, red[ww][threadIdx.x]);
+    ((T *)g.partial)[((int64_t)blockIdx.y * g.nb + blockIdx.x) * (TM * TN) + threadIdx.x] = v;
+  }
+}
+template <class T, int TM, int TN>
+__global__ void k_longk_finish(LongKArgs g) {
+  const int tiles = g.tiles_m * g.tiles_n, bz = blockIdx.x / tiles, tile = blockIdx.x - bz * tiles;
+  const int p = threadIdx.x, m = (tile / g.tiles_n) * TM + p / TN, n = (tile % g.tiles_n) * TN + p % TN;
+  if (p >= TM * TN || m >= g.M || n >= g.N) return;
+  const T *part = (const T *)g.partial + (int64_t)blockIdx.x * g.nb * (TM * TN);
+  T v = T(0);
+  for (int b = 0; b < g.nb; ++b) v = BAdd::apply(v, part[(int64_t)b * (TM * TN) + p]);
+  ((T *)g.C)[(int64_t)bz * g.c_bs + (int64_t)m * g.c_ms + (int64_t)n * g.c_ns] = v;
+}
+template <class T, int TM, int TN> int longk_run(LongKArgs a, int64_t batch) {
+  a.tiles_m = (a.M + TM - 1) / TM;
+  a.tiles_n = (a.N + TN - 1) / TN;
+  const int64_t patches = batch * a.tiles_m * a.tiles_n;
+  if (patches > 65535) return -1;
+  // blocks of >= 2048 k each (eight trips of the 256 threads), about 2048 blocks in all
+  int64_t nb = (a.K + 2047) / 2048;
+  const int64_t cap = patches >= 2048 ? 1 : 2048 / patches;
+  if (nb > cap) nb = cap;
+  a.chunk = (a.K + nb - 1) / nb;
+  a.nb = (int)((a.K + a.chunk - 1) / a.chunk);
+  void *partial = nullptr;
+  MD_TRY(mdhip_alloc((size_t)patches * a.nb * TM * TN * sizeof(T), &partial));
+  a.partial = partial;
+  hipStream_t st = md_stream();
+  MD_LAUNCH((k_longk_partial<T, TM, TN>), dim3((unsigned)a.nb, (unsigned)patches), MD_BLOCK, a);
+  k_longk_finish<T, TM, TN><<<(unsigned)patches, 64, 0, st>>>(a);
+  const int rc = MD_LAUNCH_CHECK("matmul(few outputs, long k)");
+  mdhip_free(partial);
+  return rc;
+}
+template <class T> int longk_dispatch(const LongKArgs &a, int64_t batch) {
+  if (a.M == 1 && a.N == 1) return longk_run<T, 1, 1>(a, batch);
+  if (a.M <= 2 && a.N <= 2) return longk_run<T, 2, 2>(a, batch);
+  if (a.M <= 4 && a.N <= 4) return longk_run<T, 4, 4>(a, batch);
+  if (a.N == 1) return longk_run<T, 8, 1>(a, batch);
+  if (a.M == 1) return longk_run<T, 1, 8>(a, batch);
+  return longk_run<T, 8, 8>(a, batch);
+}
+}  // namespace
+
+// -1: not such a product; otherwise the launch status. dtype: MDHIP_F32 / F64 / I32 / I64.
+int md_gemm_longk(const MdGemm &g, int dtype) {
+  if (!md_opt(MD_OPT_GEMM_SKINNY) || g.M < 1 || g.N < 1 || g.M > 128 || g.N > 128 || g.batch < 1) return -1;
+  const int64_t big = g.M > g.N ? g.M : g.N, small = g.M > g.N ? g.N : g.M;
+  if (big <= 8) {
+    if (g.K < 512) return -1;
+  } else {
+    // larger outputs: only while k dwarfs them (the tile kernels would leave most of the chip idle); float32 from 64 x 64 up has the
+    // MFMA split-k path
+    if (g.K < 8192 || g.K < 64 * big) return -1;
+    if (dtype == MDHIP_F32 && small >= 64) return -1;
+  }
+  LongKArgs a{};
+  a.A = g.a; a.B = g.b; a.C = g.c;
+  a.K = g.K;
+  a.M = (int)g.M; a.N = (int)g.N;
+  a.a_bs = g.a_bs; a.a_ms = g.a_ms; a.a_ks = g.a_ks;
+  a.b_bs = g.b_bs; a.b_ks = g.b_ks; a.b_ns = g.b_ns;
+  a.c_bs = g.c_bs; a.c_ms = g.c_ms; a.c_ns = g.c_ns;
+  switch (dtype) {
+    case MDHIP_F32: return longk_dispatch<float>(a, g.batch);
+    case MDHIP_F64: return longk_dispatch<double>(a, g.batch);
+    case MDHIP_I32: return longk_dispatch<int32_t>(a, g.batch);
+    case MDHIP_I64: return longk_dispatch<int64_t>(a, g.batch);
+  }
+  return -1;
+}
+
 // -1: not a product for these kernels (the caller goes on to the MFMA / generic paths); otherwise the launch status.
 // dtype: MDHIP_F32 / MDHIP_F64.
 int md_gemm_skinny(const MdGemm &g, int dtype) {

@@ -462,3 +462,59 @@ def test_heavy_duplicate_scatters_gpu(lib, on_gpu):
     assert on_gpu
     from minidiff_amd import ndarray as nd
     _heavy_duplicates(nd, 300000)
+
+
+def _thin_by_thin_long_k(nd, K):
+    """A few rows times a few columns over a LONG k (np.dot of two vectors, (1,K)@(K,1), (8,K)@(K,8), batched): k is cut over the
+    chip and the block partials are added in block order (csrc/skinny.hip md_gemm_longk) — integers exact, floats within the
+    summation-order bound, bit-identical run to run; transposed / strided operands by strides."""
+    rng = np.random.default_rng(12)
+    for dt in (np.float32, np.float64, np.int32, np.int64):
+        def mk(*shape):
+            return rng.standard_normal(shape).astype(dt) if np.dtype(dt).kind == "f" else rng.integers(-9, 10, shape).astype(dt)
+        for M, N in ((1, 1), (2, 1), (1, 3), (4, 4), (8, 1), (1, 8), (8, 8), (3, 5), (16, 16), (9, 3), (1, 64), (64, 1), (12, 1), (1, 100), (64, 64), (128, 33)):
+            if max(M, N) > 8 and ((K < 64 * max(M, N) and K > 10000) or K > 400000):
+                continue        # (the tile kernels' territory / host-side reference too slow to be worth it)
+            A, B = mk(M, K), mk(K, N)
+            cases = [(nd.asarray(A), nd.asarray(B), A, B)]
+            At, Bt = np.ascontiguousarray(A.T), np.ascontiguousarray(B.T)
+            cases.append((nd.asarray(At).T, nd.asarray(Bt).T, At.T, Bt.T))                       # the other unit-stride axis
+            for da, db, ha, hb in cases:
+                got = nd.matmul(da, db)
+                # (NumPy's integer matmul has no BLAS behind it — 17 s for 64 x 64 x 300,007; the float64 product of these small
+                # integers is exact: |sum| <= 81 K < 2**53)
+                ref = np.matmul(ha, hb) if np.dtype(dt).kind == "f" else np.matmul(ha.astype(np.float64), hb.astype(np.float64)).astype(dt)
+                assert got.dtype == ref.dtype and got.shape == ref.shape
+                if np.dtype(dt).kind == "f":
+                    scale = np.abs(ha).astype(np.float64) @ np.abs(hb).astype(np.float64)
+                    assert (np.abs(got.get().astype(np.float64) - ref) <= (2e-6 if dt is np.float32 else 1e-13) * scale + 1e-30).all(), (dt, M, N)
+                    assert np.array_equal(nd.matmul(da, db).get(), got.get())                      # fixed summation order
+                else:
+                    assert np.array_equal(got.get(), ref), (dt, M, N)
+        x, y = mk(K), mk(K)
+        ref = np.dot(x, y)
+        got = nd.dot(nd.asarray(x), nd.asarray(y))
+        assert got.shape == () and got.dtype == ref.dtype
+        assert np.array_equal(got.get(), ref) if np.dtype(dt).kind != "f" else abs(float(got.get()) - float(ref)) <= (2e-6 if dt is np.float32 else 1e-13) * float(np.abs(x).astype(np.float64) @ np.abs(y))
+        xs, ys = mk(2 * K)[::2], mk(3 * K)[::3]                                                    # strided vectors
+        ref = np.dot(xs, ys)
+        got = nd.dot(nd.asarray(np.ascontiguousarray(np.repeat(xs, 2)))[::2], nd.asarray(ys.copy()))
+        assert np.array_equal(got.get(), ref) if np.dtype(dt).kind != "f" else np.isclose(float(got.get()), float(ref), rtol=1e-3, atol=1e-2)
+        Ab, Bb = mk(5, 2, K), mk(5, K, 3)                                                          # batched
+        got, ref = nd.matmul(nd.asarray(Ab), nd.asarray(Bb)), (np.matmul(Ab, Bb) if np.dtype(dt).kind == "f" else np.matmul(Ab.astype(np.float64), Bb.astype(np.float64)).astype(dt))
+        assert np.array_equal(got.get(), ref) if np.dtype(dt).kind != "f" else np.allclose(got.get(), ref, rtol=1e-4, atol=1e-2 if dt is np.float32 else 1e-8)
+
+
+def test_thin_by_thin_long_k_cpu(lib, on_gpu):
+    if on_gpu:
+        pytest.skip("other twin")
+    from minidiff_amd import ndarray as nd
+    _thin_by_thin_long_k(nd, 9001)
+
+
+@pytest.mark.gpu
+def test_thin_by_thin_long_k_gpu(lib, on_gpu):
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    for K in (8192, 9001, 300007, 2_500_000):
+        _thin_by_thin_long_k(nd, K)
