@@ -2763,8 +2763,13 @@ def isin(element, test_elements, assume_unique=False, invert=False, kind=None):
     t = ravel(asarray(test_elements))
     if t.size == 0:
         return full(e.shape, py_bool(invert), dtype=np.bool_)
-    eq = equal(expand_dims(e, e.ndim), reshape(t, (1,) * e.ndim + (t.size,)))
-    res = any(eq, axis=e.ndim)
+    # element x test-element comparisons, the test elements in slabs that keep the boolean intermediate under 1 GiB
+    slab = builtins_max(1, (1 << 30) // builtins_max(e.size, 1))
+    res = None
+    for c0 in range(0, t.size, slab):
+        part = t[c0:c0 + slab]
+        hit = any(equal(expand_dims(e, e.ndim), reshape(part, (1,) * e.ndim + (part.size,))), axis=e.ndim)
+        res = hit if res is None else logical_or(res, hit)
     return logical_not(res) if invert else res
 
 

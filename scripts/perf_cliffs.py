@@ -98,4 +98,30 @@ t("dot 1d", lambda: nd.dot(nd.ravel(a2), nd.ravel(b2)))
 t("arange + reshape", lambda: nd.reshape(nd.arange(N), (R, -1)) if N % R == 0 else nd.arange(N))
 t("full / zeros_like", lambda: (nd.full((R, R), 2.5), nd.zeros_like(a2)))
 t("H2D + D2H 16 MB", lambda: nd.asarray(np.zeros(N, np.float32)).get())
+# reductions of a 3-D operand over every axis set, in permuted layouts; narrow dtypes through the index kernels; many small calls
+c3 = nd.asarray(rng.standard_normal((160, 160, 160)).astype(np.float32))
+for vn, v in (("3d", c3), ("3d perm(2,0,1)", nd.transpose(c3, (2, 0, 1))), ("3d ::2", c3[::2, :, ::2])):
+    for ax in (0, 1, 2, (0, 1), (0, 2), (1, 2)):
+        t(f"sum {vn} axis={ax}", lambda: nd.sum(v, axis=ax))
+    t(f"argmin {vn} axis=1", lambda: nd.argmin(v, axis=1))
+    t(f"mean/std {vn} axis=(0,2)", lambda: (nd.mean(v, axis=(0, 2)), nd.std(v, axis=(0, 2))))
+    t(f"any/all {vn}", lambda: (nd.any(nd.greater(v, 4.0), axis=1), nd.all(nd.less(v, 9.0))))
+for dt in (np.int8, np.float16, np.uint16):
+    x = nd.asarray(rng.integers(0, 50, (R, R)).astype(dt))
+    vr = nd.asarray(rng.integers(0, 50, (R * 2, R)).astype(dt)); ve = nd.asarray(rng.integers(0, 50, N).astype(dt))
+    t(f"gather rows {np.dtype(dt).name}", lambda: x[idx_rows])
+    t(f"gather elements {np.dtype(dt).name}", lambda: x[idx_el, idx_el2])
+    t(f"index_add rows {np.dtype(dt).name}", lambda: nd.index_add(x.copy(), idx_rows, vr))
+    t(f"index_add elements {np.dtype(dt).name}", lambda: nd.index_add(x.copy(), (idx_el, idx_el2), ve))
+    t(f"setitem elements {np.dtype(dt).name}", lambda: x.copy().__setitem__((idx_el, idx_el2), ve))
+    t(f"sum axis0 / argmax {np.dtype(dt).name}", lambda: (nd.sum(x, axis=0), nd.argmax(x, axis=1)))
+t("setitem mask <- values", lambda: a2.copy().__setitem__(m2, a2[m2]))
+t("getitem a[i, :, j] on 3-d", lambda: c3[idx_rows % 160, :, idx_rows % 160])
+t("isin 4e6 x 5000", lambda: nd.isin(i2, nd.asarray(np.arange(5000))))
+small = [nd.asarray(np.arange(10.0)) for _ in range(8)]
+t("1000 tiny adds (host overhead)", lambda: [nd.add(small[i % 8], small[(i + 1) % 8]) for i in range(1000)])
+t("1000 tiny sums", lambda: [nd.sum(small[i % 8]) for i in range(1000)])
+t("1000 tiny getitem int", lambda: [small[i % 8][3] for i in range(1000)])
+t("100 tiny fancy getitem", lambda: [small[i % 8][nd.asarray(np.array([1, 2]))] for i in range(100)])
+t("stack 200 small", lambda: nd.stack(small * 25))
 print(f"\n{len(slow)} calls over 20 ms:", slow)
