@@ -881,6 +881,7 @@ int mdhip_nonzero_fill(const mdhip_array *x, int64_t count, int64_t *out_flat) {
 int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const mdhip_array *out) {
   MD_TRY(md_check_plan(pl));
   MD_TRY(md_check_any_array(out, "gather out"));   // (a mover: any of the twelve dtypes, by element size)
+  if (dtype < 0 || dtype >= MDHIP_NUM_ALL_DTYPES || out->dtype != dtype) return md_fail(MDHIP_ETYPE, "gather: bad dtype code %d (out has %d)", dtype, out->dtype);
   if (out->ndim != pl->ndim) return md_fail(MDHIP_EVALUE, "gather: out ndim %d != plan ndim %d", out->ndim, pl->ndim);
   const int64_t total = md_plan_total(pl);
   if (total == 0) return MDHIP_OK;

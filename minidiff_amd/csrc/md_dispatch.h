@@ -307,7 +307,10 @@ static inline int md_check_plan(const mdhip_index_plan *pl) {
   if (!pl) return md_fail(MDHIP_EVALUE, "index plan is null");
   if (pl->ndim < 0 || pl->ndim > MDHIP_MAX_NDIM) return md_fail(MDHIP_EVALUE, "index plan ndim %d out of range", pl->ndim);
   if (pl->n_idx < 0 || pl->n_idx > MDHIP_MAX_NDIM) return md_fail(MDHIP_EVALUE, "index plan n_idx %d out of range", pl->n_idx);
+  for (int d = 0; d < pl->ndim; ++d)
+    if (pl->shape[d] < 0) return md_fail(MDHIP_EVALUE, "index plan extent %lld of dimension %d is negative", (long long)pl->shape[d], d);
   for (int k = 0; k < pl->n_idx; ++k) {
+    if (pl->idx_extent[k] < 0) return md_fail(MDHIP_EVALUE, "index plan: indexed axis %d has a negative extent", k);
     if (pl->idx_dtype[k] != MDHIP_I32 && pl->idx_dtype[k] != MDHIP_I64)
       return md_fail(MDHIP_EINDEX, "arrays used as indices must be of integer (or boolean) type");
     if (!pl->idx_ptr[k]) return md_fail(MDHIP_EVALUE, "index array %d is null", k);

@@ -453,6 +453,7 @@ int mdhip_matmul_bias_relu_sum(const mdhip_array *a, const mdhip_array *b, const
 int mdhip_gather(const mdhip_index_plan *pl, const void *src, int dtype, const mdhip_array *out) {
   MD_TRY(md_check_plan(pl));
   MD_TRY(md_check_any_array(out, "gather out"));
+  if (dtype < 0 || dtype >= MDHIP_NUM_ALL_DTYPES || out->dtype != dtype) return md_fail(MDHIP_ETYPE, "gather: bad dtype code %d (out has %d)", dtype, out->dtype);
   if (out->ndim != pl->ndim) return md_fail(MDHIP_EVALUE, "gather: out ndim mismatch");
   size_t es = md_dtype_size(dtype);
   int64_t n = md_plan_total(pl), pos[MDHIP_MAX_NDIM];
@@ -471,6 +472,9 @@ int mdhip_scatter(const mdhip_index_plan *pl, void *dst, int dtype, const mdhip_
   if (!val) return md_fail(MDHIP_EVALUE, "scatter: null value");
   if (!val->is_scalar) MD_TRY(md_check_any_array(val, "scatter val"));
   if (!val->is_scalar && val->dtype != dtype) return md_fail(MDHIP_ETYPE, "scatter: value dtype must match destination");
+  if (!val->is_scalar && val->ndim != pl->ndim) return md_fail(MDHIP_EVALUE, "scatter: value ndim mismatch");
+  if (mode != MDHIP_SCATTER_SET && mode != MDHIP_SCATTER_ADD) return md_fail(MDHIP_EVALUE, "scatter: bad mode %d", mode);
+  if (dtype < 0 || dtype >= MDHIP_NUM_ALL_DTYPES) return md_fail(MDHIP_ETYPE, "scatter: bad dtype code %d", dtype);
   size_t es = md_dtype_size(dtype);
   int64_t n = md_plan_total(pl), pos[MDHIP_MAX_NDIM];
   for (int64_t i = 0; i < n; ++i) {  // bounds first: NumPy raises before writing
