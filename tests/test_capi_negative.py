@@ -136,6 +136,72 @@ def _hostile(lib_path, device=False):
     return n_err
 
 
+def _random_vm_programs(lib_path, n_programs, seed):
+    """Random bytecode for the fused-expression interpreter (include/mdhip.h mdhip_vm_program, csrc/md_vm.h): arbitrary ctrl words,
+    instruction / leaf counts and compute dtypes. md_vm_check must reject whatever could underflow or overrun the four-slot stack or
+    name a missing leaf; what it accepts must run to completion on valid leaves. Returns (accepted, rejected)."""
+    from minidiff_amd import _capi
+    raw = C.CDLL(lib_path)
+    raw.mdhip_init(0)
+    rng = np.random.default_rng(seed)
+    leaves = [np.ascontiguousarray(rng.standard_normal((6, 5)).astype(np.float32)) for _ in range(_capi.VM_MAX_LEAVES)]
+    out = np.zeros((6, 5), np.float32)
+    outd = _capi.ArrayDesc()
+    outd.data, outd.dtype, outd.ndim = out.ctypes.data, _capi.F32, 2
+    outd.shape[0], outd.shape[1], outd.strides[0], outd.strides[1] = 6, 5, 5, 1
+    ok = bad = 0
+    for _ in range(n_programs):
+        pr = _capi.VmProgram()
+        style = rng.integers(0, 3)
+        pr.n_instr = int(rng.integers(-2, _capi.VM_MAX_INSTR + 3)) if style == 0 else int(rng.integers(1, 12))
+        pr.n_leaves = int(rng.integers(-1, _capi.VM_MAX_LEAVES + 2)) if style == 0 else int(rng.integers(1, _capi.VM_MAX_LEAVES + 1))
+        pr.compute_dtype = int(rng.choice([_capi.F32, _capi.F32, _capi.F32, _capi.F64, _capi.I32, 77]))
+        for i in range(_capi.VM_MAX_INSTR):
+            pr.ctrl[i] = int(rng.integers(0, 1 << 32))
+            pr.imm[i] = float(rng.standard_normal())
+        if style == 2:      # a stack-consistent program (so that the interpreter itself runs), one word in ten corrupted afterwards
+            words, depth, nl = [], 0, max(pr.n_leaves, 1)
+            ctrl = lambda kind, op, ls, ll, rs, rl: kind | (op << 3) | (ls << 8) | (ll << 10) | (rs << 13) | (rl << 15)   # noqa: E731
+            UN = [u for u in range(18) if u != _capi.U_INVERT]
+            for _i in range(int(rng.integers(1, 30))):
+                choices = ["push"] if depth == 0 else (["push"] if depth < 4 else []) + ["unary", "binary_leaf"] + (["binary_stack"] if depth >= 2 else []) + (["where"] if depth >= 3 else [])
+                c = str(rng.choice(choices))
+                if c == "push":
+                    words.append(ctrl(0, 0, 0, 0, int(rng.integers(1, 3)), int(rng.integers(0, nl)))); depth += 1
+                elif c == "unary":
+                    words.append(ctrl(1, int(rng.choice(UN)), 0, 0, 0, 0))
+                elif c == "binary_leaf":
+                    words.append(ctrl(2, int(rng.integers(0, 18)), 0, 0, int(rng.integers(1, 3)), int(rng.integers(0, nl))))
+                elif c == "binary_stack":
+                    words.append(ctrl(2, int(rng.integers(0, 18)), 0, 0, 0, 0)); depth -= 1
+                else:
+                    words.append(ctrl(3, 0, 0, 0, 0, 0)); depth -= 2
+            while depth > 1:
+                words.append(ctrl(2, int(rng.integers(0, 9)), 0, 0, 0, 0)); depth -= 1
+            words = words[:_capi.VM_MAX_INSTR]
+            pr.n_instr = len(words)
+            for i, w in enumerate(words):
+                pr.ctrl[i] = w if rng.random() > 0.1 else w ^ (1 << int(rng.integers(0, 20)))
+        for k in range(_capi.VM_MAX_LEAVES):
+            d = pr.leaves[k]
+            d.data, d.dtype, d.ndim = leaves[k].ctypes.data, _capi.F32, 2
+            d.shape[0], d.shape[1], d.strides[0], d.strides[1] = 6, 5, 5, 1
+        if pr.compute_dtype == _capi.F64:
+            continue        # (float32 leaves and out: keep the accepted programs type-consistent)
+        rc = raw.mdhip_vm_eval(C.byref(pr), C.byref(outd))
+        assert rc in (0, 1, 2, 3, 4, 5), rc
+        ok += rc == 0
+        bad += rc != 0
+    return ok, bad
+
+
+def test_random_vm_programs_are_rejected_or_run(lib, on_gpu):
+    if on_gpu:
+        pytest.skip("host-memory descriptors: CPU double only")
+    ok, bad = _random_vm_programs(os.path.join(ROOT, "oracle", "_build", "libmdhip_host.so"), 4000, 1)
+    assert ok > 20 and bad > 1000, (ok, bad)
+
+
 def test_hostile_descriptors_get_error_codes(lib, on_gpu):
     if on_gpu:
         pytest.skip("host-memory descriptors: CPU double only")
@@ -158,8 +224,9 @@ def test_hostile_descriptors_on_the_sanitized_double(on_gpu):
     if not os.path.isabs(asan_rt) or not os.path.exists(asan_rt):
         pytest.skip("no libasan in this toolchain")
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    asan_so = os.path.join(ROOT, "oracle", "_build", "libmdhip_host_asan.so")
     code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {HERE!r}); import test_capi_negative as t; "
-            f"print('errors', t._hostile({os.path.join(ROOT, 'oracle', '_build', 'libmdhip_host_asan.so')!r}))")
+            f"print('errors', t._hostile({asan_so!r})); print('vm', t._random_vm_programs({asan_so!r}, 3000, 2))")
     env = dict(os.environ, LD_PRELOAD=asan_rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "errors" in p.stdout and "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stdout[-1500:] + p.stderr[-3000:]
