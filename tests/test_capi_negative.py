@@ -136,7 +136,7 @@ def _hostile(lib_path, device=False):
     return n_err
 
 
-def _random_vm_programs(lib_path, n_programs, seed):
+def _random_vm_programs(lib_path, n_programs, seed, device=False):
     """Random bytecode for the fused-expression interpreter (include/mdhip.h mdhip_vm_program, csrc/md_vm.h): arbitrary ctrl words,
     instruction / leaf counts and compute dtypes. md_vm_check must reject whatever could underflow or overrun the four-slot stack or
     name a missing leaf; what it accepts must run to completion on valid leaves. Returns (accepted, rejected)."""
@@ -146,8 +146,14 @@ def _random_vm_programs(lib_path, n_programs, seed):
     rng = np.random.default_rng(seed)
     leaves = [np.ascontiguousarray(rng.standard_normal((6, 5)).astype(np.float32)) for _ in range(_capi.VM_MAX_LEAVES)]
     out = np.zeros((6, 5), np.float32)
+    if device:
+        from minidiff_amd import ndarray as nd
+        keep = [nd.asarray(x) for x in leaves] + [nd.asarray(out)]
+        leaf_ptr, out_ptr = [k.ptr for k in keep[:-1]], keep[-1].ptr
+    else:
+        leaf_ptr, out_ptr = [x.ctypes.data for x in leaves], out.ctypes.data
     outd = _capi.ArrayDesc()
-    outd.data, outd.dtype, outd.ndim = out.ctypes.data, _capi.F32, 2
+    outd.data, outd.dtype, outd.ndim = out_ptr, _capi.F32, 2
     outd.shape[0], outd.shape[1], outd.strides[0], outd.strides[1] = 6, 5, 5, 1
     ok = bad = 0
     for _ in range(n_programs):
@@ -184,7 +190,7 @@ def _random_vm_programs(lib_path, n_programs, seed):
                 pr.ctrl[i] = w if rng.random() > 0.1 else w ^ (1 << int(rng.integers(0, 20)))
         for k in range(_capi.VM_MAX_LEAVES):
             d = pr.leaves[k]
-            d.data, d.dtype, d.ndim = leaves[k].ctypes.data, _capi.F32, 2
+            d.data, d.dtype, d.ndim = leaf_ptr[k], _capi.F32, 2
             d.shape[0], d.shape[1], d.strides[0], d.strides[1] = 6, 5, 5, 1
         if pr.compute_dtype == _capi.F64:
             continue        # (float32 leaves and out: keep the accepted programs type-consistent)
@@ -192,6 +198,8 @@ def _random_vm_programs(lib_path, n_programs, seed):
         assert rc in (0, 1, 2, 3, 4, 5), rc
         ok += rc == 0
         bad += rc != 0
+    if device:
+        nd._lib().sync()
     return ok, bad
 
 
@@ -215,6 +223,13 @@ def test_hostile_descriptors_get_error_codes_gpu(lib, on_gpu):
     assert on_gpu
     n = _hostile(os.path.join(ROOT, "minidiff_amd", "libmdhip.so"), device=True)
     assert n >= 60
+
+
+@pytest.mark.gpu
+def test_random_vm_programs_are_rejected_or_run_gpu(lib, on_gpu):
+    assert on_gpu
+    ok, bad = _random_vm_programs(os.path.join(ROOT, "minidiff_amd", "libmdhip.so"), 3000, 3, device=True)
+    assert ok > 100 and bad > 1000, (ok, bad)
 
 
 def test_hostile_descriptors_on_the_sanitized_double(on_gpu):
