@@ -18,9 +18,10 @@ exception it raises for a combination it rejects) comes from running the SAME Nu
 dummies of the operands' dtypes — no promotion table restated here.
 
 In the promote path uint64 rides in int64 with the same bits: a wrapped function that looks at VALUES (not just bits)
-first checks that no element is >= 2**63 and raises TypeError otherwise — loud, not wrong. Only `isin` still does: the
-products and the nonzero family give the same bits either way (_BITS), a call whose NumPy loop is float64 (uint64 @ int64,
-mean / std of integers) converts each element straight from its own type, and the native path has unsigned 64-bit loops.
+first checks that no element is >= 2**63 and raises TypeError otherwise — loud, not wrong. No function of the table is left
+that does: the products and the nonzero family give the same bits either way (_BITS), a call whose NumPy loop is float64
+(uint64 @ int64, mean / std of integers) converts each element straight from its own type, `isin` is composed of the native
+comparisons, and the native path has unsigned 64-bit loops.
 
 Nothing on a BASELINE path uses these types; the cost on the wide paths is one flag test per call (`install`)."""
 from __future__ import annotations
@@ -52,7 +53,7 @@ _BITS = {"matmul", "dot", "tensordot", "nonzero", "flatnonzero", "argwhere"}
 # index_add, take_/put_along_axis — move or add in the array's own type: csrc/index.hip.)
 COMPUTE = [
     "mean", "std", "matmul", "dot", "tensordot",
-    "concatenate", "stack", "tile", "repeat", "split", "isin", "nonzero", "flatnonzero", "argwhere",
+    "concatenate", "stack", "tile", "repeat", "split", "nonzero", "flatnonzero", "argwhere",
 ]
 
 
@@ -105,7 +106,7 @@ def install(ns: dict):
                 if to_f64 and x.dtype.kind in "iu":
                     return convert(x, np.dtype(np.float64))
                 w = convert(x, _WIDE[x.dtype])
-                if x.dtype == _U64 and name not in _MOVERS and name not in _BITS and x.size and bool(ns["any"](ns["less"](w, 0)).item()):
+                if x.dtype == _U64 and name not in _MOVERS and name not in _BITS and name not in _STATS and x.size and bool(ns["any"](ns["less"](w, 0)).item()):
                     raise TypeError(f"uint64 values >= 2**63 are not supported by the MI355X backend in {name}()")
                 return w
             return x
@@ -118,7 +119,7 @@ def install(ns: dict):
         if isinstance(x, np.ndarray) and x.dtype in _WIDE:
             if to_f64 and x.dtype.kind in "iu":
                 return x.astype(np.float64)
-            if x.dtype == _U64 and name not in _MOVERS and name not in _BITS and x.size and int(x.max()) >= 1 << 63:
+            if x.dtype == _U64 and name not in _MOVERS and name not in _BITS and name not in _STATS and x.size and int(x.max()) >= 1 << 63:
                 raise TypeError(f"uint64 values >= 2**63 are not supported by the MI355X backend in {name}()")
             return x.astype(_WIDE[x.dtype])
         if isinstance(x, (list, tuple)):

@@ -432,6 +432,8 @@ class DeviceArray(_fp.ArrayBase if _fp is not None else object):
 
     @property
     def is_c_contiguous(self) -> py_bool:
+        if 0 in self.shape:
+            return True      # (an empty array is contiguous both ways, as in NumPy)
         acc = 1
         for n, s in zip(reversed(self.shape), reversed(self._strides)):
             if n == 1:

@@ -113,7 +113,7 @@ REDUCE = ["sum", "prod", "max", "min", "any", "all", "mean"]
 
 def one_case(rng, big):
     kind = rng.choice(["unary", "binary", "where", "reduce", "arg", "gather", "scatter", "matmul", "astype",
-                       "inplace", "concat", "along", "misc"])
+                       "inplace", "concat", "along", "misc", "kwargs"])
     dt = DTYPES[int(rng.integers(0, len(DTYPES)))]
     shape = rand_shape(rng, big)
     h = rand_array(rng, shape, dt)
@@ -375,6 +375,57 @@ def one_case(rng, big):
                     g64, e64 = g64[fin], e64[fin]
                 if e64.size:
                     assert np.abs(g64 - e64).max() <= tol * (float(np.abs(hh).max()) + 1.0), f"std {h.shape} ax={ax}"
+        elif kind == "kwargs":
+            # keyword forms of the table's functions (out=, dtype=, order=, invert=, scalar-boolean keys ..) on the drawn view
+            k = int(rng.integers(0, 7))
+            if k == 0 and h.dtype != np.bool_:          # reduction with dtype= and out=
+                name = str(rng.choice(["sum", "prod"]))
+                axis = None if h.ndim == 0 else int(rng.integers(0, h.ndim))
+                rdt = np.float64 if h.dtype.kind == "f" else np.int64
+                hh = h if name == "sum" or h.dtype.kind != "f" else (np.sign(h) * (0.999 + 0.002 * np.abs(np.tanh(np.nan_to_num(h.astype(np.float64)))))).astype(h.dtype)
+                hh = np.nan_to_num(hh, nan=0.25, posinf=2.0, neginf=-2.0).astype(h.dtype) if h.dtype.kind == "f" else hh
+                exp = getattr(np, name)(hh, axis=axis, dtype=rdt)
+                o = nd.zeros(exp.shape, exp.dtype)
+                got = getattr(nd, name)(nd.asarray(hh), axis=axis, dtype=rdt, out=o)
+                assert got is o
+                if rdt is np.int64:
+                    assert np.array_equal(np.asarray(got), exp), f"{name}(dtype, out) {h.shape}{h.dtype}"
+                else:
+                    assert np.allclose(np.asarray(got), exp, rtol=1e-9, atol=1e-9 * (np.abs(hh.astype(np.float64)).sum() + 1)), f"{name}(dtype, out) {h.shape}{h.dtype}"
+            elif k == 1:                                 # ufunc with out= of a wider dtype
+                odt = np.float64 if h.dtype.kind in "fiub" else h.dtype
+                exp = np.zeros(h.shape, odt); np.add(h, h, out=exp)
+                o = nd.zeros(h.shape, odt)
+                assert nd.add(d, d, out=o) is o
+                close(o, exp, f"add(out={np.dtype(odt).name}) {h.shape}{h.dtype}")
+            elif k == 2:                                 # memory orders
+                order = str(rng.choice(["C", "F", "A", "K"]))
+                close(nd.ravel(d, order=order), np.ravel(h, order=order), f"ravel {order} {h.shape}{h.dtype}")
+                c, e = nd.copy(d, order=order), np.copy(h, order=order)
+                close(c, e, f"copy {order} {h.shape}{h.dtype}")
+                assert c.is_c_contiguous == e.flags.c_contiguous and c.T.is_c_contiguous == e.flags.f_contiguous, f"copy {order} layout {h.shape}"
+                close(nd.flatten(d, order=order), h.flatten(order=order), f"flatten {order} {h.shape}{h.dtype}")
+            elif k == 3:                                 # scalar booleans, None and Ellipsis in keys
+                parts = [bool(rng.integers(0, 2)), None, Ellipsis, slice(None, None, int(rng.choice([1, 2, -1])))]
+                key = tuple(parts[int(i)] for i in rng.permutation(4)[: int(rng.integers(1, 4))])
+                if sum(1 for q in key if isinstance(q, slice)) > h.ndim:
+                    return
+                close(d[key], h[key], f"getitem {key!r} {h.shape}{h.dtype}")
+            elif k == 4 and h.dtype.kind in "iu" and h.size:
+                te = rng.integers(-3, 4, int(rng.integers(0, 6))).astype(h.dtype)
+                inv = bool(rng.integers(0, 2))
+                close(nd.isin(d, nd.asarray(te), invert=inv), np.isin(h, te, invert=inv), f"isin invert={inv} {h.shape}{h.dtype}")
+            elif k == 5 and h.size and h.ndim:
+                order = str(rng.choice(["C", "F"]))
+                flat = rng.integers(0, h.size, (5,))
+                for g, e in zip(nd.unravel_index(nd.asarray(flat), h.shape, order=order), np.unravel_index(flat, h.shape, order=order)):
+                    close(g, e, f"unravel_index {order} {h.shape}")
+            elif k == 6 and h.dtype != np.bool_:         # mean with an integer dtype=, std with ddof
+                if h.ndim == 0 or h.size == 0:
+                    return
+                axis = int(rng.integers(0, h.ndim))
+                if h.dtype.kind in "iu":
+                    close(nd.mean(d, axis=axis, dtype=np.int64), np.mean(h, axis=axis, dtype=np.int64), f"mean(dtype=int64) {h.shape}{h.dtype}")
         elif kind == "astype":
             to = DTYPES[int(rng.integers(0, len(DTYPES)))]
             if h.dtype.kind == "f" and np.dtype(to).kind in "iu":

@@ -91,8 +91,8 @@ def test_narrow_dtype_gpu(lib, on_gpu, dt):
 def test_uint64_whole_range_in_the_native_path(lib):
     """Elementwise arithmetic, comparisons, where and the reductions have unsigned 64-bit loops of their own (csrc/md_narrow.h: the
     uint64 carrier): values >= 2**63 give NumPy's results; gathers / scatters move and add in the array's own type. The functions
-    that still go promote -> wide kernel -> demote (narrow.COMPUTE: products, statistics) carry uint64 in int64 and refuse such
-    values loudly."""
+    that still go promote -> wide kernel -> demote (narrow.COMPUTE: products, statistics, builders) give the same bits either way
+    or convert each element from its own type first: no function of the table refuses such values any more."""
     from minidiff_amd import ndarray as nd
     big = np.array([1, 2 ** 63 + 5, 7, 2 ** 64 - 1, 2 ** 63], dtype=np.uint64)
     oth = np.array([3, 2 ** 63 + 1, 2 ** 64 - 1, 2, 5], dtype=np.uint64)
@@ -132,8 +132,8 @@ def test_uint64_whole_range_in_the_native_path(lib):
     assert np.array_equal(nd.tensordot(nd.asarray(m), nd.asarray(k.T.copy()), axes=1).get(), np.tensordot(m, k.T.copy(), axes=1))
     z = big.copy(); z[2] = 0
     assert all(np.array_equal(g.get(), r) for g, r in zip(nd.nonzero(nd.asarray(z)), np.nonzero(z)))
-    with pytest.raises(TypeError, match="uint64"):                                          # the one function that still looks: loud
-        nd.isin(d, o)
+    assert np.array_equal(nd.isin(d, o).get(), np.isin(big, oth)) and np.array_equal(nd.isin(d, o, invert=True).get(), np.isin(big, oth, invert=True))
+    assert np.array_equal(nd.mean(d, dtype=np.int64).get(), np.mean(big, dtype=np.int64))    # an integer dtype=: NumPy casts (wraps) first
 
 
 NATIVE_CASES = [("multiply", np.int8, np.int8), ("add", np.uint8, np.uint8), ("subtract", np.int16, np.int16), ("less", np.uint16, np.uint16),
