@@ -137,10 +137,17 @@ class HostComm:
             from . import _capi
 
             lib = _capi.current()
-            if lib is None or lib.target == _capi.PRODUCT_TARGET:
-                raise TypeError("HostComm reduces host memory only (tests); use RcclComm for device arrays")
             if not arr.is_c_contiguous:
                 raise ValueError("allreduce needs a contiguous buffer")
+            if lib is None or lib.target == _capi.PRODUCT_TARGET:
+                # a REHEARSAL on real device memory (scripts/rehearse_two_ranks_one_gpu.sh: two ranks sharing one GPU, where RCCL refuses
+                # to build a communicator): staged through the host — copy out, gloo, copy back. Never a measured path.
+                from . import ndarray as nd
+
+                host = arr.get()
+                self.dist.all_reduce(self.torch.from_numpy(host))
+                arr[...] = nd.asarray(host)
+                return
             lib.sync()
             raw = (C.c_char * arr.nbytes).from_address(arr.ptr)
             arr = np.frombuffer(raw, dtype=arr.dtype)
