@@ -162,7 +162,11 @@ def test_bench_distributed_path_on_one_gpu(on_gpu, comm, workload):
                         "--workload", workload, "--size", "512", "--no-cpu-baseline", "--comm", comm, "--detail", detail]
                        + (["--allow-torch-comm"] if comm == "torch" else []),
                        env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    if p.returncode != 0:      # keep the whole story where a later reader finds it (this test failed once on a cold box and passed ever after)
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", f"bench_dist_failure_{workload}_{comm}.log"), "w") as f:
+            f.write(f"rc {p.returncode}\n--- stdout\n{p.stdout}\n--- stderr\n{p.stderr}\n")
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-6000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
     head = json.load(open(detail))["head"]
     assert line["config"]["collective"] == ("rccl-direct" if comm == "rccl" else "rccl-torch"), line["config"]
