@@ -1,0 +1,90 @@
+"""A small training loop end to end — the way a user of the reference would drive the backend for more than one sweep: a two-layer
+MLP with a softmax-free squared loss, plain SGD written with the tape's own ops under no_grad, 40 steps, parameters living in device
+memory throughout. The device engine (HipBackendTable) against the NumPy-table engine (oracle/numpy_table.py: the reference's
+arithmetic) on the same seeds: losses and final parameters within fp32 tolerance; then the same loop with the sweep replayed from a
+hipGraph by SweepCache (GPU only) — parameter updates written INTO the resident arrays must be picked up by every replay."""
+import numpy as np
+import pytest
+
+gpu = pytest.mark.gpu
+
+
+def _loop(md, steps, cache=None, dtype=np.float32):
+    rng = np.random.default_rng(21)
+    X = md.Tensor(rng.standard_normal((96, 24)).astype(dtype))
+    Y = md.Tensor(rng.standard_normal((96, 5)).astype(dtype))
+    W1 = md.Tensor((rng.standard_normal((24, 32)) * 0.2).astype(dtype), allow_grad=True)
+    b1 = md.Tensor(np.zeros(32, dtype), allow_grad=True)
+    W2 = md.Tensor((rng.standard_normal((32, 5)) * 0.2).astype(dtype), allow_grad=True)
+    b2 = md.Tensor(np.zeros(5, dtype), allow_grad=True)
+    params = [W1, b1, W2, b2]
+    lr = dtype(0.05)
+
+    def sweep():
+        for p in params:
+            p.grad = None
+        h = md.tanh(X @ W1 + b1)
+        out = h @ W2 + b2
+        loss = md.mean((out - Y) ** 2)
+        loss.backward()
+        return {"loss": loss, "grads": [p.grad for p in params]}
+
+    losses = []
+    for _ in range(steps):
+        res = cache.run(sweep) if cache is not None else sweep()
+        losses.append(float(res["loss"].as_numpy()))
+        for p, g in zip(params, res["grads"]):
+            # the update goes INTO the parameter's own array (a replayed graph reads that memory)
+            p._data[...] = md.backend.subtract(p._data, md.backend.multiply(g._data, lr))
+    return np.array(losses), [np.asarray(p.as_numpy()).copy() for p in params]
+
+
+def _engines(lib):
+    from minidiff_amd.hip_backend import HipBackendTable
+    from minidiff_amd.tape import build_engine
+    from oracle.numpy_table import NumpyOracleTable
+    return build_engine(HipBackendTable, "dev"), build_engine(NumpyOracleTable, "np")
+
+
+def _check(lib, lazy):
+    from minidiff_amd import ndarray as nd
+    dev, ref = _engines(lib)
+    prev = nd.set_lazy(lazy)
+    try:
+        for dtype, tol in ((np.float32, 2e-5), (np.float64, 1e-12)):
+            l_ref, p_ref = _loop(ref, 40, dtype=dtype)
+            l_dev, p_dev = _loop(dev, 40, dtype=dtype)
+            assert l_ref[-1] < 0.7 * l_ref[0]                                     # it does train
+            assert np.allclose(l_dev, l_ref, rtol=tol, atol=tol), (dtype, np.abs(l_dev - l_ref).max())
+            for a, b in zip(p_dev, p_ref):
+                assert a.dtype == b.dtype and np.allclose(a, b, rtol=20 * tol, atol=20 * tol), dtype
+    finally:
+        nd.set_lazy(prev)
+
+
+@pytest.mark.parametrize("lazy", [False, True], ids=["eager", "lazy"])
+def test_training_loop_matches_numpy_engine_cpu(lib, on_gpu, lazy):
+    if on_gpu:
+        pytest.skip("other twin")
+    _check(lib, lazy)
+
+
+@gpu
+@pytest.mark.parametrize("lazy", [False, True], ids=["eager", "lazy"])
+def test_training_loop_matches_numpy_engine_gpu(lib, on_gpu, lazy):
+    assert on_gpu
+    _check(lib, lazy)
+
+
+@gpu
+def test_training_loop_replayed_from_a_graph_gpu(lib, on_gpu):
+    assert on_gpu
+    from minidiff_amd.graph import SweepCache
+    dev, ref = _engines(lib)
+    l_ref, p_ref = _loop(ref, 40)
+    with SweepCache(dev, validate_every=0) as cache:
+        l_dev, p_dev = _loop(dev, 40, cache=cache)
+        assert cache.stats["captured"] == 1 and cache.stats["replayed"] >= 35 and cache.stats["uncapturable"] == 0, cache.stats
+    assert np.allclose(l_dev, l_ref, rtol=2e-5, atol=2e-5)
+    for a, b in zip(p_dev, p_ref):
+        assert np.allclose(a, b, rtol=4e-4, atol=4e-4)
