@@ -124,4 +124,18 @@ t("1000 tiny sums", lambda: [nd.sum(small[i % 8]) for i in range(1000)])
 t("1000 tiny getitem int", lambda: [small[i % 8][3] for i in range(1000)])
 t("100 tiny fancy getitem", lambda: [small[i % 8][nd.asarray(np.array([1, 2]))] for i in range(100)])
 t("stack 200 small", lambda: nd.stack(small * 25))
+# skinny geometries: very short rows / columns, unit extents, inner extent 1
+for shp in ((N // 3, 3), (3, N // 3), (N // 2, 2), (1, N), (N, 1), (N // 64, 8, 8), (8, N // 64, 8), (8, 8, N // 64), (N // 5, 5, 1)):
+    s_ = nd.asarray(rng.standard_normal(shp).astype(np.float32))
+    nm = "x".join(str(v) for v in shp)
+    for ax in range(len(shp)):
+        t(f"sum {nm} axis={ax}", lambda: nd.sum(s_, axis=ax))
+        t(f"argmax {nm} axis={ax}", lambda: nd.argmax(s_, axis=ax))
+        t(f"max {nm} axis={ax} keepdims, subtract", lambda: nd.subtract(s_, nd.max(s_, axis=ax, keepdims=True)))
+    t(f"sum {nm} all", lambda: nd.sum(s_))
+    t(f"T copy {nm}", lambda: nd.copy(s_.T, order="C"))
+    t(f"std {nm} axis=-1", lambda: nd.std(s_, axis=-1))
+    t(f"add last-axis vector {nm}", lambda: nd.add(s_, nd.asarray(np.ones(shp[-1], np.float32))))
+    t(f"multiply first-axis column {nm}", lambda: nd.multiply(s_, nd.asarray(np.ones(shp[:1] + (1,) * (len(shp) - 1), np.float32))))
+    t(f"where {nm}", lambda: nd.where(nd.greater(s_, 0), s_, 0.0))
 print(f"\n{len(slow)} calls over 20 ms:", slow)

@@ -518,3 +518,30 @@ def test_thin_by_thin_long_k_gpu(lib, on_gpu):
     from minidiff_amd import ndarray as nd
     for K in (8192, 9001, 300007, 2_500_000):
         _thin_by_thin_long_k(nd, K)
+
+
+def _long_strided_arg_lines(nd):
+    """argmax / argmin down a handful of long STRIDED lines (the two columns of a 2,000,000 x 2 array): gathered into rows first
+    (ndarray._arg_reduce) — same indices, first occurrence among ties, keepdims, views."""
+    rng = np.random.default_rng(4)
+    for shp, ax in (((70000, 2), 0), ((70000, 3), 0), ((2, 70000, 3), 1), ((70000, 2, 2), 0), ((3, 70000), 1), ((70000, 2), -2), ((200000, 5, 1), 0)):
+        a = rng.integers(0, 50, shp).astype(np.float32)      # many ties
+        for kd in (False, True):
+            for f in ("argmax", "argmin"):
+                r, e = getattr(nd, f)(nd.asarray(a), axis=ax, keepdims=kd).get(), getattr(np, f)(a, axis=ax, keepdims=kd)
+                assert r.shape == e.shape and np.array_equal(r, e), (shp, ax, kd, f)
+        assert np.array_equal(nd.argmax(nd.asarray(a)[::2], axis=ax).get(), np.argmax(a[::2], axis=ax))
+
+
+def test_long_strided_arg_lines_cpu(lib, on_gpu):
+    if on_gpu:
+        pytest.skip("other twin")
+    from minidiff_amd import ndarray as nd
+    _long_strided_arg_lines(nd)
+
+
+@pytest.mark.gpu
+def test_long_strided_arg_lines_gpu(lib, on_gpu):
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    _long_strided_arg_lines(nd)
