@@ -21,6 +21,7 @@
   X(PINNED_CAP, "pinned_cap", (int64_t)4 << 30, 'c')   /* bytes of page-locked host memory outstanding at most */               \
   X(JIT, "jit", 1, 'c')                                /* 0: never compile fused kernels at run time (interpreter only) */      \
   X(JIT_VERBOSE, "jit_verbose", 0, 'c')                /* print hiprtc logs of failed compilations */                           \
+  X(INDEX_DEFER, "index_defer", 0, 'c')                /* 1: gathers / scatters never read their bounds verdict back (see index.hip) */ \
   /* experiments (MDHIP_EXPERIMENTS=1, or mdhip_debug_set_option) */                                                            \
   X(JIT_MIN, "jit_min", 1 << 18, 'x')                  /* elements from which a fused program is specialised */                 \
   X(COMM_PRIORITY, "comm_priority", 0, 'x')            /* 1: the collective stream gets the high-priority queue */             \
