@@ -13,7 +13,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SLICE = ["test_shim.py", "test_large_shape_paths.py", "test_lazy_fusion.py", "test_golden_device.py", "test_fuzz_differential.py",
-         "test_device_rng.py", "test_ops_reference_style.py", "test_fastpath.py", "test_std_fused.py", "test_graph.py", "test_narrow_dtypes.py"]
+         "test_device_rng.py", "test_ops_reference_style.py", "test_fastpath.py", "test_std_fused.py", "test_graph.py", "test_narrow_dtypes.py", "test_api_differential.py", "test_training_loop.py"]
 
 
 def test_cpu_suite_slice_on_the_sanitized_double(on_gpu):
