@@ -61,6 +61,9 @@ else:
 # Lazy fusion of elementwise chains (minidiff_amd/lazy.py) is opt-in; eager —
 # one kernel per backend call, the reference's execution model — is the default.
 _LAZY = os.environ.get("MDHIP_LAZY", "0") == "1"
+# lazy mode: results with fewer elements than this are computed eagerly all the same (a fused program saves HBM passes; below ~10^4
+# elements there are none to save and building the program costs more host time than the kernels it replaces). 0: fuse everything.
+_LAZY_MIN = int(os.environ.get("MDHIP_LAZY_MIN", "0"))
 
 
 def set_lazy(flag: bool) -> bool:
@@ -967,7 +970,7 @@ def _binary(ufunc, code, a, b, out=None):
                 raise ValueError(f"non-broadcastable output operand with shape {out.shape} doesn't match the broadcast shape {shape}")
             _copy_into(out, const)      # (bool casts safely into every dtype)
             return out
-    if _LAZY and out is None and not ((a_arr and a._code >= _NARROW_MIN) or (b_arr and b._code >= _NARROW_MIN)):
+    if _LAZY and out is None and _prod(shape) >= _LAZY_MIN and not ((a_arr and a._code >= _NARROW_MIN) or (b_arr and b._code >= _NARROW_MIN)):
         # (storage-only operands are never leaves of a fused program: the interpreter and the generated kernels read the five compute dtypes)
         pcdt = _FLOAT_DT.get(cdt)
         if pcdt is None and cdt.kind == "b" and code >= _capi.B_LAND:
@@ -1070,7 +1073,7 @@ def _unary(ufunc, code, x):
             dtype_code(dt)
         _RESOLVE_CACHE[key] = loop
     # (sin(bool array): NumPy answers in float16 — computed in float32, rounded once, as NumPy's own half loops do: csrc/narrow.hip)
-    if _LAZY and code != _capi.U_INVERT and x.size > 0 and x._code < _NARROW_MIN:
+    if _LAZY and code != _capi.U_INVERT and x.size > 0 and x.size >= _LAZY_MIN and x._code < _NARROW_MIN:
         pcdt = _FLOAT_DT.get(loop[0])
         if pcdt is not None and (loop[1] == loop[0] or loop[1] == np.bool_) and x.dtype.kind in "fb" or \
                 (pcdt is not None and x.dtype.kind == "i" and pcdt == _capi.F64):
@@ -1310,7 +1313,7 @@ def where(condition, x=None, y=None):
     shape = arrs[0].shape
     for v in arrs[1:]:
         shape = _broadcast_shapes(shape, v.shape)
-    if _LAZY and _prod(shape) > 0 and not builtins_any(v._code >= _NARROW_MIN for v in arrs):
+    if _LAZY and _prod(shape) > 0 and _prod(shape) >= _LAZY_MIN and not builtins_any(v._code >= _NARROW_MIN for v in arrs):
         pcdt = _FLOAT_DT.get(odt)
         if pcdt is not None:
             res = _lazy_node(_lz.WHERE, 0, (c, a, b), pcdt, shape, odt)
