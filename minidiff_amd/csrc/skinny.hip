@@ -401,24 +401,39 @@ __global__ void __launch_bounds__(MD_BLOCK) k_longk_partial(LongKArgs g) {
     ((T *)g.partial)[((int64_t)blockIdx.y * g.nb + blockIdx.x) * (TM * TN) + threadIdx.x] = v;
   }
 }
+// one block per patch: the 256 threads split into G = 256 / (TM TN) groups, group q adds the partials of blocks q, q + G, q + 2G, ..
+// for its output (independent loads; one thread walking 2048 dependent ones took 80 us), then the group sums are added in group
+// order — a fixed order, so the result is bit-identical run to run
 template <class T, int TM, int TN>
-__global__ void k_longk_finish(LongKArgs g) {
+__global__ void __launch_bounds__(MD_BLOCK) k_longk_finish(LongKArgs g) {
+  constexpr int P = TM * TN, G = MD_BLOCK / P;
+  __shared__ T sums[G][P];
   const int tiles = g.tiles_m * g.tiles_n, bz = blockIdx.x / tiles, tile = blockIdx.x - bz * tiles;
-  const int p = threadIdx.x, m = (tile / g.tiles_n) * TM + p / TN, n = (tile % g.tiles_n) * TN + p % TN;
-  if (p >= TM * TN || m >= g.M || n >= g.N) return;
-  const T *part = (const T *)g.partial + (int64_t)blockIdx.x * g.nb * (TM * TN);
-  T v = T(0);
-  for (int b = 0; b < g.nb; ++b) v = BAdd::apply(v, part[(int64_t)b * (TM * TN) + p]);
-  ((T *)g.C)[(int64_t)bz * g.c_bs + (int64_t)m * g.c_ms + (int64_t)n * g.c_ns] = v;
+  const int p = threadIdx.x % P, q = threadIdx.x / P;
+  const T *part = (const T *)g.partial + (int64_t)blockIdx.x * g.nb * P;
+  if (q < G) {
+    T v = T(0);
+    for (int b = q; b < g.nb; b += G) v = BAdd::apply(v, part[(int64_t)b * P + p]);
+    sums[q][p] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < P) {
+    const int m = (tile / g.tiles_n) * TM + threadIdx.x / TN, n = (tile % g.tiles_n) * TN + threadIdx.x % TN;
+    if (m < g.M && n < g.N) {
+      T v = sums[0][threadIdx.x];
+      for (int qq = 1; qq < G; ++qq) v = BAdd::apply(v, sums[qq][threadIdx.x]);
+      ((T *)g.C)[(int64_t)bz * g.c_bs + (int64_t)m * g.c_ms + (int64_t)n * g.c_ns] = v;
+    }
+  }
 }
 template <class T, int TM, int TN> int longk_run(LongKArgs a, int64_t batch) {
   a.tiles_m = (a.M + TM - 1) / TM;
   a.tiles_n = (a.N + TN - 1) / TN;
   const int64_t patches = batch * a.tiles_m * a.tiles_n;
   if (patches > 65535) return -1;
-  // blocks of >= 2048 k each (eight trips of the 256 threads), about 2048 blocks in all
-  int64_t nb = (a.K + 2047) / 2048;
-  const int64_t cap = patches >= 2048 ? 1 : 2048 / patches;
+  // blocks of >= 4096 k each (sixteen trips of the 256 threads), about 1024 blocks in all (four per CU)
+  int64_t nb = (a.K + 4095) / 4096;
+  const int64_t cap = patches >= 1024 ? 1 : 1024 / patches;
   if (nb > cap) nb = cap;
   a.chunk = (a.K + nb - 1) / nb;
   a.nb = (int)((a.K + a.chunk - 1) / a.chunk);
@@ -427,7 +442,7 @@ template <class T, int TM, int TN> int longk_run(LongKArgs a, int64_t batch) {
   a.partial = partial;
   hipStream_t st = md_stream();
   MD_LAUNCH((k_longk_partial<T, TM, TN>), dim3((unsigned)a.nb, (unsigned)patches), MD_BLOCK, a);
-  k_longk_finish<T, TM, TN><<<(unsigned)patches, 64, 0, st>>>(a);
+  k_longk_finish<T, TM, TN><<<(unsigned)patches, MD_BLOCK, 0, st>>>(a);
   const int rc = MD_LAUNCH_CHECK("matmul(few outputs, long k)");
   mdhip_free(partial);
   return rc;
