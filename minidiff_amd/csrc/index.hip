@@ -735,7 +735,10 @@ static int scatter_typed(const mdhip_index_plan *pl, int64_t total, void *dst, c
   for (int d = 0; d < MDHIP_MAX_NDIM; ++d) v.strides[d] = (!val->is_scalar && d < pl->ndim) ? val->strides[d] : 0;
   T s = val->is_scalar ? md_scalar_as<T>(val) : T();
   constexpr bool is_fp = md_is_float<T>::value;
-  if (total <= 4096) {  // walk in order on one lane: exactly NumPy's loop
+  // a few positions: walk them in order on one lane — exactly NumPy's loop, one launch. (Up to round 4 this served 4096 positions:
+  // ~0.9 us per position of dependent loads, 1.8 ms for the 2000-element put_along_axis of a max / min backward; the sorted paths
+  // below cost ~70 us of small launches whatever the count.)
+  if (total <= 128) {
     if (mode == MDHIP_SCATTER_SET) k_scatter_serial<T, MDHIP_SCATTER_SET><<<1, 64, 0, st>>>(*pl, total, (T *)dst, v, s);
     else k_scatter_serial<T, MDHIP_SCATTER_ADD><<<1, 64, 0, st>>>(*pl, total, (T *)dst, v, s);
     return MD_LAUNCH_CHECK("scatter(serial)");

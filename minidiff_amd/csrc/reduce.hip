@@ -519,6 +519,32 @@ __global__ void __launch_bounds__(MD_BLOCK) k_arg_block(MdRedPlan pl, const void
   }
 }
 
+// Contiguous reduced axis, rows of a few dozen to a thousand elements (max / min backward of a matrix over its last axis):
+// a WAVE per row — the lanes stride the row (coalesced), meet their indices in increasing order (so "strictly better" keeps the
+// first of equal values) and are merged by RArg::combine. One THREAD per row walked 268 elements 1 KiB apart from its neighbour's:
+// 277 GB/s, 3.9 ms for 10^6 rows of 268 where max takes 0.27.
+template <bool IsMax, class T>
+__global__ void __launch_bounds__(MD_BLOCK) k_arg_rows_wave(MdRedPlan pl, const T *__restrict__ x, int64_t *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t o = wave; o < pl.n_out; o += n_waves) {
+    int64_t xo, oo;
+    md_red_kept_offsets(pl, o, &xo, &oo);
+    const T *row = x + xo;
+    md_argpair<T> acc = RArg<IsMax>::template identity<T>();
+    for (int64_t r = lane; r < pl.n_red; r += 64) {
+      const T v = row[r];
+      if (acc.i == INT64_MAX || RArg<IsMax>::better(v, acc.v)) { acc.v = v; acc.i = r; }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      md_argpair<T> other{md_shfl_down(acc.v, d), md_shfl_down(acc.i, d)};
+      acc = RArg<IsMax>::combine(acc, other);
+    }
+    if (lane == 0) out[oo] = acc.i;
+  }
+}
+
 // Contiguous reduced axis (argmax over the last axis): one block per output, 16-B loads, two in
 // flight per lane. A lane meets its indices in increasing order, so "strictly better" keeps the
 // first of equal values (and the first NaN), as np.argmax does; lanes are merged with RArg::combine.
@@ -1156,6 +1182,12 @@ struct HipExec {
         mdhip_free(pi);
         return rc;
       }
+    }
+    if (x->dtype == md_dtype_of<T>::value && pl.nr == 1 && pl.rx[0] == 1 && pl.n_red >= 24 && pl.n_red < 1024 && pl.n_out >= 64) {
+      int64_t blocks = ceil_div(pl.n_out, MD_BLOCK / 64);
+      if (blocks > 8 * MD_NUM_CUS) blocks = 8 * MD_NUM_CUS;
+      MD_LAUNCH((k_arg_rows_wave<IsMax, T>), (unsigned)blocks, MD_BLOCK, pl, (const T *)x->data, (int64_t *)out->data);
+      return MD_LAUNCH_CHECK("argreduce(rows,wave)");
     }
     if (pl.n_red >= 512 && pl.n_out < (1ll << 30)) {
       k_arg_block<IsMax, T><<<(unsigned)pl.n_out, MD_BLOCK, 0, st>>>(pl, x->data, x->dtype, (int64_t *)out->data);

@@ -545,3 +545,35 @@ def test_long_strided_arg_lines_gpu(lib, on_gpu):
     assert on_gpu
     from minidiff_amd import ndarray as nd
     _long_strided_arg_lines(nd)
+
+
+def _mid_length_arg_rows(nd):
+    """argmax / argmin over the last axis for rows of 24 .. 1023 elements (a wave per row, csrc/reduce.hip k_arg_rows_wave): first of
+    equal values, the first NaN, every compute dtype, strided row starts, 3-D."""
+    rng = np.random.default_rng(9)
+    for rows, cols in ((300, 24), (1000, 64), (4097, 268), (700, 1023), (65, 100)):
+        for dt in (np.float32, np.float64, np.int32, np.int64, np.bool_):
+            a = (rng.random((rows, cols)) > 0.5) if dt is np.bool_ else rng.integers(-4, 5, (rows, cols)).astype(dt)      # many ties
+            if np.dtype(dt).kind == "f":
+                a[rng.integers(0, rows, rows // 3), rng.integers(0, cols, rows // 3)] = np.nan
+            d = nd.asarray(a)
+            for f in ("argmax", "argmin"):
+                assert np.array_equal(getattr(nd, f)(d, axis=-1).get(), getattr(np, f)(a, axis=-1)), (rows, cols, dt, f)
+                assert np.array_equal(getattr(nd, f)(d[::3], axis=1, keepdims=True).get(), getattr(np, f)(a[::3], axis=1, keepdims=True)), (rows, cols, dt, f)
+    b = rng.integers(0, 3, (40, 50, 130)).astype(np.float32)
+    assert np.array_equal(nd.argmax(nd.asarray(b), axis=2).get(), np.argmax(b, axis=2))
+    assert np.array_equal(nd.argmin(nd.asarray(b)[:, ::2], axis=-1).get(), np.argmin(b[:, ::2], axis=-1))
+
+
+def test_mid_length_arg_rows_cpu(lib, on_gpu):
+    if on_gpu:
+        pytest.skip("other twin")
+    from minidiff_amd import ndarray as nd
+    _mid_length_arg_rows(nd)
+
+
+@pytest.mark.gpu
+def test_mid_length_arg_rows_gpu(lib, on_gpu):
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    _mid_length_arg_rows(nd)

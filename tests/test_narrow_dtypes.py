@@ -252,7 +252,7 @@ def _index_and_compare(nd):
     rng = np.random.default_rng(77)
     for dt in NARROW:
         kind = np.dtype(dt).kind
-        # (three columns: element-granular order — serial below 4096 positions, sorted by destination above; sixteen columns: whole
+        # (three columns: element-granular order — serial up to 128 positions, sorted by destination above; sixteen columns: whole
         # rows, ordered at row granularity)
         for n, m, w in ((40, 25, 3), (3000, 9000, 3), (300, 6000, 16)):
             if kind == "f":
