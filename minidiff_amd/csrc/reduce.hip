@@ -177,6 +177,24 @@ __global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows_wave(MdRedPlan pl, con
   if (lane == 0) dst[oo] = md_cast<Tdst>(acc);
 }
 
+// .. and the same wave per output for rows the kernel above does not take: 1- and 2-byte element types (any / all of a bool matrix
+// over its last axis, sums of int8), rows that do not start on 16-B boundaries, operands of another dtype than the accumulator —
+// lanes stride the row element by element through md_load (the dtype switch is wave-uniform). The block-per-output kernel gave a
+// 268-byte row 256 threads and its own block: 10^6 such rows of bool took 1.28 ms (210 GB/s).
+template <class R, class Tacc, class Tdst>
+__global__ void __launch_bounds__(MD_BLOCK) k_reduce_rows_wave_any(MdRedPlan pl, const void *x, int xdt, Tdst *__restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t o = wave; o < pl.n_out; o += n_waves) {
+    int64_t xo, oo;
+    md_red_kept_offsets(pl, o, &xo, &oo);
+    Tacc acc = R::template identity<Tacc>();
+    for (int64_t r = lane; r < pl.n_red; r += 64) acc = R::combine(acc, md_load<Tacc>(x, xdt, xo + r));
+    acc = md_wave_reduce<R>(acc);
+    if (lane == 0) dst[oo] = md_cast<Tdst>(acc);
+  }
+}
+
 // Full reduction of a contiguous array of the accumulator's own type (the loss `sum` of the BASELINE graphs): the rows
 // kernel above without its plan — a lane strides the 16-B vectors of the whole grid, two in flight — and the ticket finish
 // (md_ticket.h, two-level: ~1000 blocks arrive). 24.0 -> 22.5 us on cfg4's 128 MiB against the general kernel: the plan's
@@ -937,6 +955,14 @@ struct HipExec {
         else MD_LAUNCH((k_reduce_rows_wave<R, Tacc, To, 8>), grid, MD_BLOCK, pl, xp, (To *)out->data);
         return MD_LAUNCH_CHECK("reduce(rows,wave)");
       }
+    }
+    // (rows of the accumulator's own 4- / 8-byte type from 256 elements on keep the block kernel's peeled 16-B loads)
+    const bool typed_vec = sizeof(Tacc) >= 4 && x->dtype == md_dtype_of<Tacc>::value;
+    if (pl.nr == 1 && pl.rx[0] == 1 && n_red >= 16 && n_red <= 4096 && (!typed_vec || n_red < 256) && n_out >= 256 && md_opt(MD_OPT_ROWS_WAVE) != 0) {
+      int64_t blocks = ceil_div(n_out, MD_BLOCK / 64);
+      if (blocks > 8 * MD_NUM_CUS) blocks = 8 * MD_NUM_CUS;
+      MD_LAUNCH((k_reduce_rows_wave_any<R, Tacc, To>), (unsigned)blocks, MD_BLOCK, pl, x->data, x->dtype, (To *)out->data);
+      return MD_LAUNCH_CHECK("reduce(rows,wave,any type)");
     }
     if (cols_ok && (!rows_ok || n_out >= 1024)) {
       if constexpr (sizeof(Tacc) >= 4 && md_same<Tacc, To>::value) {
