@@ -1103,7 +1103,7 @@ def main(entry=None):
         out = rounded(line)
         drop = list(DROP_ORDER)
         text = json.dumps(out, separators=(",", ":"))
-        while len(text) > 2000 and drop:
+        while len(text) > 1950 and drop:
             out["roofline"].pop(drop.pop(0), None)
             text = json.dumps(out, separators=(",", ":"))
         try:
