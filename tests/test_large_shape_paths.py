@@ -552,8 +552,8 @@ def _mid_length_arg_rows(nd):
     equal values, the first NaN, every compute dtype, strided row starts, 3-D."""
     rng = np.random.default_rng(9)
     for rows, cols in ((300, 24), (1000, 64), (4097, 268), (700, 1023), (65, 100)):
-        for dt in (np.float32, np.float64, np.int32, np.int64, np.bool_):
-            a = (rng.random((rows, cols)) > 0.5) if dt is np.bool_ else rng.integers(-4, 5, (rows, cols)).astype(dt)      # many ties
+        for dt in (np.float32, np.float64, np.int32, np.int64, np.bool_, np.int8, np.uint16, np.float16, np.uint64):
+            a = (rng.random((rows, cols)) > 0.5) if dt is np.bool_ else rng.integers(-4 if np.dtype(dt).kind != "u" else 0, 5, (rows, cols)).astype(dt)      # many ties
             if np.dtype(dt).kind == "f":
                 a[rng.integers(0, rows, rows // 3), rng.integers(0, cols, rows // 3)] = np.nan
             d = nd.asarray(a)
