@@ -1759,6 +1759,10 @@ def _fused_reduce(code, a, mask, kshape, out_dtype):
         if res is not None:
             return res
     cols = nd == 2 and mask == 1 and a.shape[0] > 1 and a.shape[1] > 1 and a.shape[1] % 4 == 0
+    if cols and not full and a.shape[1] < 512 and a.shape[0] >= 65536:
+        # a TALL expression with few columns: the fused column kernels find their parallelism across columns (4,000,000 x 16: 6.2 ms
+        # fused against 0.4 ms; 1,000,000 x 268: 1.7 against 1.0) — one fused evaluation, then the eager column reduction
+        return None
     if not (full or cols):
         return None
     if cols and not full and a.size >= _DEFER_COLS_MIN and a.shape[1] % 1024 == 0 and a.shape[0] >= 512:
