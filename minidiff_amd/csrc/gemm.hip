@@ -1697,6 +1697,50 @@ struct HipExec {
       const int rc = md_gemm_skinny(g_in, md_same<T, float>::value ? MDHIP_F32 : MDHIP_F64);
       if (rc >= 0) return rc;
     }
+    if constexpr (md_same<T, float>::value) {
+      // A product whose output is a few dozen 128 x 128 tiles under a LONG k (the weight gradient of a 1000-wide layer over a
+      // 300,000-row batch: 64 tiles, a quarter of the chip, 32-52 TFLOP/s): k is cut into 2-4 ranges that run as the BATCH of one
+      // launch of the ordinary kernels (a range is a batch entry: a_bs / b_bs step along k, c_bs from partial to partial), a short
+      // second launch takes what the equal ranges leave over, and the partials are added in range order (k_gemm_splitk_sum).
+      const int64_t t128 = ((g_in.M + 127) / 128) * ((g_in.N + 127) / 128), t64 = ((g_in.M + 63) / 64) * ((g_in.N + 63) / 64);
+      // (both sides at most 2048: the row panels dp.GradSync cuts a wide weight gradient into — 512 x 4096 — keep the plain product's
+      // summation order, so panelled and un-panelled gradients stay bit-identical)
+      if (md_opt(MD_OPT_GEMM_SPLITK) && g_in.batch == 1 && t64 >= MD_NUM_CUS && t128 <= MD_NUM_CUS / 2 && g_in.M <= 2048 && g_in.N <= 2048 && g_in.K >= 4096 &&
+          g_in.K >= 2 * (g_in.M > g_in.N ? g_in.M : g_in.N)) {
+        int64_t splits = MD_NUM_CUS / t128;
+        if (splits > 4) splits = 4;
+        const int64_t k_chunk = g_in.K / splits / 32 * 32, k_rem = g_in.K - splits * k_chunk;
+        if (splits >= 2 && k_chunk >= 1024) {
+          const int64_t parts = splits + (k_rem > 0 ? 1 : 0);
+          void *partial = nullptr;
+          MD_TRY(mdhip_alloc((size_t)(parts * g_in.M * g_in.N) * sizeof(float), &partial));
+          MdGemm g2 = g_in;
+          g2.batch = splits;
+          g2.K = k_chunk;
+          g2.a_bs = k_chunk * g_in.a_ks;
+          g2.b_bs = k_chunk * g_in.b_ks;
+          g2.c = partial;
+          g2.c_bs = g_in.M * g_in.N; g2.c_ms = g_in.N; g2.c_ns = 1;
+          int rc = gemm<float>(g2);
+          if (rc == MDHIP_OK && k_rem > 0) {
+            MdGemm g3 = g2;
+            g3.batch = 1;
+            g3.K = k_rem;
+            g3.a = (const float *)g_in.a + splits * k_chunk * g_in.a_ks;
+            g3.b = (const float *)g_in.b + splits * k_chunk * g_in.b_ks;
+            g3.c = (float *)partial + splits * g_in.M * g_in.N;
+            rc = gemm<float>(g3);
+          }
+          if (rc == MDHIP_OK) {
+            k_gemm_splitk_sum<<<md_grid_for(g_in.M * g_in.N), MD_BLOCK, 0, md_stream()>>>((const float *)partial, (int)parts, 1, g_in.M, g_in.N, (float *)g_in.c,
+                                                                                     g_in.c_bs, g_in.c_ms, g_in.c_ns);
+            rc = MD_LAUNCH_CHECK("matmul(f32, k ranges as a batch)");
+          }
+          mdhip_free(partial);
+          return rc;
+        }
+      }
+    }
     MdGemm g = g_in;
     bool c_rows_unit = false;
     if constexpr (md_same<T, float>::value) {

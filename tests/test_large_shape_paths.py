@@ -577,3 +577,27 @@ def test_mid_length_arg_rows_gpu(lib, on_gpu):
     assert on_gpu
     from minidiff_amd import ndarray as nd
     _mid_length_arg_rows(nd)
+
+
+@pytest.mark.gpu
+def test_few_tiles_long_k_products_gpu(lib, on_gpu):
+    """A few dozen output tiles under a long k (the weight gradient of a 1000-wide layer over a large batch): k ranges run as the batch
+    of one launch, partials added in range order (csrc/gemm.hip HipExec::gemm). All three layouts, a k that does not divide (the
+    remainder launch), integer-valued operands exact, a strided destination."""
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    rng = np.random.default_rng(6)
+    for M, K, N in ((1000, 40000, 1000), (1024, 32768 + 96, 768), (900, 20000, 1100)):
+        A = rng.integers(-3, 4, (M, K)).astype(np.float32)
+        B = rng.integers(-3, 4, (K, N)).astype(np.float32)
+        ref = (A.astype(np.float64) @ B.astype(np.float64)).astype(np.float32)          # exact: |sum| < 2**24
+        dA, dB = nd.asarray(A), nd.asarray(B)
+        dAt, dBt = nd.asarray(np.ascontiguousarray(A.T)), nd.asarray(np.ascontiguousarray(B.T))
+        for name, got in (("NN", nd.matmul(dA, dB)), ("NT", nd.matmul(dA, dBt.T)), ("TN", nd.matmul(dAt.T, dB)), ("TT", nd.matmul(dAt.T, dBt.T))):
+            assert np.array_equal(got.get(), ref), (M, K, N, name)
+        X = rng.standard_normal((M, K)).astype(np.float32); Y = rng.standard_normal((K, N)).astype(np.float32)
+        got = nd.matmul(nd.asarray(np.ascontiguousarray(X.T)).T, nd.asarray(Y)).get()
+        ref64 = X.astype(np.float64) @ Y.astype(np.float64)
+        scale = np.abs(X).astype(np.float64) @ np.abs(Y).astype(np.float64)
+        assert (np.abs(got - ref64) <= 2e-6 * scale + 1e-30).all(), (M, K, N)
+        assert np.array_equal(nd.matmul(nd.asarray(np.ascontiguousarray(X.T)).T, nd.asarray(Y)).get(), got)      # fixed order
