@@ -601,3 +601,49 @@ def test_few_tiles_long_k_products_gpu(lib, on_gpu):
         scale = np.abs(X).astype(np.float64) @ np.abs(Y).astype(np.float64)
         assert (np.abs(got - ref64) <= 2e-6 * scale + 1e-30).all(), (M, K, N)
         assert np.array_equal(nd.matmul(nd.asarray(np.ascontiguousarray(X.T)).T, nd.asarray(Y)).get(), got)      # fixed order
+
+
+def _three_axis_broadcasts(nd):
+    """(B, R, C) op (B, 1, C) / (1, R, 1) / a sliced (B, R, C) view: iteration spaces that keep three axes take the 16-byte
+    vector kernel of elementwise.hip (k_binary_rows3); bit-identical to NumPy in every loop dtype it serves, both operand orders,
+    and the shapes next to its conditions (inner extent not a multiple of 4, misaligned base, small totals) still agree."""
+    rng = np.random.default_rng(5)
+    for dt in (np.float32, np.float64, np.int32, np.int64):
+        def mk(*shape):
+            return (rng.standard_normal(shape) * 50).astype(dt)
+        for B, R, C in ((16, 96, 128), (16, 96, 132), (16, 96, 130), (3, 5, 8192)):
+            x = mk(B, R, C)
+            dx = nd.asarray(x)
+            for o in (mk(B, 1, C), mk(1, R, 1), mk(B, 1, 1), mk(B, R, 1), mk(R, 1)):
+                do = nd.asarray(o)
+                for name in ("multiply", "subtract", "maximum"):
+                    np.testing.assert_array_equal(getattr(nd, name)(dx, do).get(), getattr(np, name)(x, o), err_msg=f"{dt.__name__} {name} {x.shape} {o.shape}")
+                    np.testing.assert_array_equal(getattr(nd, name)(do, dx).get(), getattr(np, name)(o, x), err_msg=f"{dt.__name__} {name} {o.shape} {x.shape}")
+            np.testing.assert_array_equal(nd.multiply(dx, 3).get(), x * 3)
+    # strided operands reach the kernel as views, not copies
+    base = rng.standard_normal((8, 70, 264)).astype(np.float32)
+    db = nd.asarray(base)
+    y = rng.standard_normal((8, 1, 256)).astype(np.float32)
+    dy = nd.asarray(y)
+    for sl in ((slice(None), slice(2, 66), slice(4, 260)), (slice(None), slice(2, 66), slice(1, 257)), (slice(None), slice(0, 64), slice(0, 256)),
+               (slice(None), slice(None, None, -1), slice(8, 264)), (slice(None), slice(0, 64), slice(0, 512, 2))):
+        np.testing.assert_array_equal(nd.add(db[sl], dy[:, :, :base[sl].shape[2]]).get(), base[sl] + y[:, :, :base[sl].shape[2]])
+        np.testing.assert_array_equal(nd.true_divide(dy[:, :, :base[sl].shape[2]], db[sl]).get(), y[:, :, :base[sl].shape[2]] / base[sl])
+        np.testing.assert_array_equal(nd.multiply(db[sl], db[sl]).get(), base[sl] * base[sl])
+    # the broadcast operand is itself a broadcast view; the two big operands are different views of one base
+    np.testing.assert_array_equal(nd.add(db[:, :64, :256], nd.broadcast_to(dy[:1], (8, 64, 256))).get(), base[:, :64, :256] + y[:1])
+    np.testing.assert_array_equal(nd.subtract(db[:, :64, :256], db[:, 6:70, 8:264]).get(), base[:, :64, :256] - base[:, 6:70, 8:264])
+
+
+def test_three_axis_broadcasts_cpu(lib, on_gpu):
+    if on_gpu:
+        pytest.skip("other twin")
+    from minidiff_amd import ndarray as nd
+    _three_axis_broadcasts(nd)
+
+
+@pytest.mark.gpu
+def test_three_axis_broadcasts_vector_kernel_gpu(lib, on_gpu):
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    _three_axis_broadcasts(nd)
