@@ -38,50 +38,72 @@ __global__ void __launch_bounds__(MD_BLOCK) k_unary_generic(MdIter it, const voi
   }
 }
 
-// ---- three-level iteration spaces with a contiguous inner axis -------------------------------------------------------------
-// (B, R, C) * (B, 1, C), (B, R, C) * (1, R, 1): the broadcasts of normalisation layers do not collapse to (rows, inner), so they
-// took the element-by-element generic kernel (768 GB/s at 64 x 512 x 512). Here a lane owns one 16-B vector of the output's inner
-// axis: (r0, r1, c) from two divisions, operands read as a vector (inner stride 1) or one value (inner stride 0), the result
-// stored as a vector. Same-type arithmetic on float32 / float64 / int32 / int64.
-struct Rows3 {
-  int64_t d0, d1, nv;        // extents of the two outer axes, vectors per inner row
-  int64_t a0, a1, b0, b1;    // outer strides (elements)
-  int a_in, b_in;            // inner stride 0 / 1
+// ---- iteration spaces of three / four axes with a contiguous inner axis ---------------------------------------------------
+// (B, R, C) * (B, 1, C), (B, R, C) * (1, R, 1), (N, C, H, W) * (1, C, 1, W), any call on a sliced 3-D view: the broadcasts of
+// normalisation layers do not collapse to (rows, inner), so they took the element-by-element generic kernels (690-990 GB/s at
+// 64 x 512 x 512). Here a lane owns one vector of four elements of the output's inner axis: the outer position from two or three
+// divisions (32-bit when the launch allows), every operand read as a vector (inner stride 1) or one value (inner stride 0) in
+// its own storage type, the result stored as a vector. Operands are of the loop's storage type (the mask of `where`: bool).
+struct AxesGeom {
+  int64_t e0, e1, e2, nv, rows;   // extents of the outer axes (e0 = 1 for three axes), vectors per inner row, e0 * e1 * e2
+  int64_t st[3][3];               // operand k, outer axis j: stride in elements
+  int in[3];                      // inner stride 0 / 1
 };
-template <class F, class T>
-__global__ void __launch_bounds__(MD_BLOCK) k_binary_rows3(Rows3 g, const T *__restrict__ a, T sa, const T *__restrict__ b, T sb, T *__restrict__ out) {
-  const int64_t total = g.d0 * g.d1 * g.nv, gs = (int64_t)gridDim.x * blockDim.x;
+template <class T, class C>
+__device__ __forceinline__ void md_axes_load(const T *__restrict__ p, C s, int in, int64_t off, int64_t c, C (&r)[4]) {
+  if (p == nullptr) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = s;
+  } else if (in) {
+    const MdVec<T, 4> t = *reinterpret_cast<const MdVec<T, 4> *>(p + off + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = md_cast<C>(t.v[j]);
+  } else {
+    const C t = md_cast<C>(p[off]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = t;
+  }
+}
+template <class F> struct AxUnary {
+  template <class C0, class C1, class C2> static __device__ __forceinline__ auto apply(C0 a, C1, C2) { return F::apply(a); }
+};
+template <class F> struct AxBinary {
+  template <class C0, class C1, class C2> static __device__ __forceinline__ auto apply(C0 a, C1 b, C2) { return F::apply(a, b); }
+};
+struct AxWhere {
+  template <class C0, class C1, class C2> static __device__ __forceinline__ C1 apply(C0 c, C1 a, C2 b) { return c ? a : b; }
+};
+template <class Op, int NIN, class To, class T0, class C0, class T1, class C1, class T2, class C2>
+__global__ void __launch_bounds__(MD_BLOCK) k_ew_axes(AxesGeom g, const T0 *__restrict__ p0, C0 s0, const T1 *__restrict__ p1, C1 s1,
+                                                     const T2 *__restrict__ p2, C2 s2, To *__restrict__ out) {
+  const int64_t total = g.rows * g.nv, gs = (int64_t)gridDim.x * blockDim.x;
+  const bool narrow = total < (1ll << 31);
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gs) {
-    const int64_t row = v / g.nv, cv = v - row * g.nv, r0 = row / g.d1, r1 = row - r0 * g.d1, c = cv << 2;
-    T x[4], y[4];
-    if (a == nullptr) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = sa;
-    } else if (g.a_in) {
-      const MdVec<T, 4> t = *reinterpret_cast<const MdVec<T, 4> *>(a + r0 * g.a0 + r1 * g.a1 + c);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = t.v[j];
+    int64_t row, r0 = 0, r1, r2;
+    if (narrow) {
+      const uint32_t w = (uint32_t)v / (uint32_t)g.nv, q = w / (uint32_t)g.e2;
+      row = w;
+      r2 = w - q * (uint32_t)g.e2;
+      r1 = q;
+      if (g.e0 != 1) { const uint32_t t = q / (uint32_t)g.e1; r0 = t; r1 = q - t * (uint32_t)g.e1; }
     } else {
-      const T t = a[r0 * g.a0 + r1 * g.a1];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = t;
+      row = v / g.nv;
+      const int64_t q = row / g.e2;
+      r2 = row - q * g.e2;
+      r1 = q;
+      if (g.e0 != 1) { r0 = q / g.e1; r1 = q - r0 * g.e1; }
     }
-    if (b == nullptr) {
+    const int64_t c = (v - row * g.nv) << 2;
+    C0 x[4];
+    C1 y[4] = {};
+    C2 z[4] = {};
+    md_axes_load(p0, s0, g.in[0], r0 * g.st[0][0] + r1 * g.st[0][1] + r2 * g.st[0][2], c, x);
+    if constexpr (NIN > 1) md_axes_load(p1, s1, g.in[1], r0 * g.st[1][0] + r1 * g.st[1][1] + r2 * g.st[1][2], c, y);
+    if constexpr (NIN > 2) md_axes_load(p2, s2, g.in[2], r0 * g.st[2][0] + r1 * g.st[2][1] + r2 * g.st[2][2], c, z);
+    MdVec<To, 4> r;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) y[j] = sb;
-    } else if (g.b_in) {
-      const MdVec<T, 4> t = *reinterpret_cast<const MdVec<T, 4> *>(b + r0 * g.b0 + r1 * g.b1 + c);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) y[j] = t.v[j];
-    } else {
-      const T t = b[r0 * g.b0 + r1 * g.b1];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) y[j] = t;
-    }
-    MdVec<T, 4> r;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r.v[j] = F::apply(x[j], y[j]);
-    *reinterpret_cast<MdVec<T, 4> *>(out + row * (g.nv << 2) + c) = r;
+    for (int j = 0; j < 4; ++j) r.v[j] = md_to_out<To>(Op::apply(x[j], y[j], z[j]));
+    *reinterpret_cast<MdVec<To, 4> *>(out + row * (g.nv << 2) + c) = r;
   }
 }
 
@@ -466,6 +488,49 @@ template <class Body, int U> static int launch_fast(const Body &body, const Fast
   return MD_LAUNCH_CHECK(what);
 }
 
+// k_ew_axes eligibility: three or four collapsed axes, a dense output, every array operand of the dtype the kernel reads it in with
+// its inner axis contiguous (aligned for vector loads) or broadcast. `out_k` = the output's slot in the iterator.
+static bool axes_geom(const MdIter &it, int out_k, const mdhip_array *out, size_t out_esize, const mdhip_array *const *ops, const int *dtypes,
+                      const size_t *esizes, int n_in, AxesGeom *g) {
+  if (it.ndim != 3 && it.ndim != 4) return false;
+  const int nd = it.ndim, sh = 4 - nd;   // outer axis j of the kernel = iterator axis j - sh
+  const int64_t inner = it.shape[nd - 1];
+  if ((inner & 3) || it.total < (1 << 16) || it.strides[out_k][nd - 1] != 1) return false;
+  int64_t dense = inner;
+  for (int d = nd - 2; d >= 0; --d) {
+    if (it.strides[out_k][d] != dense) return false;
+    dense *= it.shape[d];
+  }
+  auto aligned = [](const void *p, size_t es) { return ((uintptr_t)p % (es * 4 > 16 ? 16 : es * 4)) == 0; };
+  if (!aligned(out->data, out_esize)) return false;
+  g->e0 = nd == 4 ? it.shape[0] : 1;
+  g->e1 = it.shape[1 - sh];
+  g->e2 = it.shape[2 - sh];
+  g->nv = inner >> 2;
+  g->rows = g->e0 * g->e1 * g->e2;
+  for (int k = 0; k < 3; ++k) {
+    g->in[k] = 0;
+    for (int j = 0; j < 3; ++j) g->st[k][j] = 0;
+  }
+  bool any = false;
+  for (int k = 0; k < n_in; ++k) {
+    const mdhip_array *x = ops[k];
+    if (x->is_scalar) continue;
+    any = true;
+    if (x->dtype != dtypes[k]) return false;
+    const int64_t is = it.strides[k][nd - 1];
+    if (is != 0 && is != 1) return false;
+    g->in[k] = (int)is;
+    for (int j = sh; j < 3; ++j) {
+      const int64_t st = it.strides[k][j - sh];
+      if (is == 1 && (st & 3)) return false;
+      g->st[k][j] = st;
+    }
+    if (is == 1 && !aligned(x->data, esizes[k])) return false;
+  }
+  return any;
+}
+
 struct HipExec {
   // ------------------------------------------------------------------ unary ----
   template <class F, class Tc, class To, class Tx, int MX>
@@ -505,6 +570,17 @@ struct HipExec {
           case MDHIP_BOOL: MD_CAST_FROM(b8) break;
         }
 #undef MD_CAST_FROM
+      }
+    }
+    {
+      AxesGeom ag;
+      const mdhip_array *ops[1] = {x};
+      const int dts[1] = {md_dtype_of<Tx>::value};
+      const size_t ess[1] = {sizeof(Tx)};
+      if (axes_geom(it, 1, out, sizeof(To), ops, dts, ess, 1, &ag)) {
+        MD_LAUNCH((k_ew_axes<AxUnary<F>, 1, To, Tx, Tc, Tx, Tc, Tx, Tc>), md_grid_for(it.total >> 2), MD_BLOCK, ag, (const Tx *)x->data, sx, (const Tx *)nullptr, sx,
+                  (const Tx *)nullptr, sx, (To *)out->data);
+        return MD_LAUNCH_CHECK("unary(axes, vectors)");
       }
     }
     int64_t B, R, Cn, xb, xc;
@@ -558,24 +634,16 @@ struct HipExec {
         if (try_binary_fast<F, Tc, To, b8, Ts>(it, g, a, b, out, sa, sb, &status)) return status;
       }
     }
-    if constexpr (md_same<Tc, To>::value && md_same<Tc, Ts>::value && sizeof(Tc) >= 4 && md_same<decltype(F::apply(Tc(), Tc())), Tc>::value) {
-      // three collapsed axes, the output dense, the inner axis contiguous (or broadcast) in every operand: 16-B vectors
-      if (it.ndim == 3 && !(a->is_scalar && b->is_scalar) && (it.shape[2] & 3) == 0 && it.strides[2][2] == 1 && it.strides[2][1] == it.shape[2] &&
-          it.strides[2][0] == it.shape[1] * it.shape[2] && ((uintptr_t)out->data & 15) == 0 && it.total >= (1 << 16)) {
-        auto ok = [&](const mdhip_array *x, int k) {
-          if (x->is_scalar) return true;
-          if (x->dtype != md_dtype_of<Tc>::value) return false;
-          const int64_t is = it.strides[k][2];
-          if (is == 0) return true;
-          return is == 1 && ((uintptr_t)x->data & 15) == 0 && (it.strides[k][0] & 3) == 0 && (it.strides[k][1] & 3) == 0;
-        };
-        if (ok(a, 0) && ok(b, 1)) {
-          Rows3 g3{it.shape[0], it.shape[1], it.shape[2] >> 2, it.strides[0][0], it.strides[0][1], it.strides[1][0], it.strides[1][1],
-                   a->is_scalar ? 0 : (int)it.strides[0][2], b->is_scalar ? 0 : (int)it.strides[1][2]};
-          MD_LAUNCH((k_binary_rows3<F, Tc>), md_grid_for(it.total >> 2), MD_BLOCK, g3, a->is_scalar ? nullptr : (const Tc *)a->data, sa,
-                    b->is_scalar ? nullptr : (const Tc *)b->data, sb, (Tc *)out->data);
-          return MD_LAUNCH_CHECK("binary(three axes, vectors)");
-        }
+    if (!(a->is_scalar && b->is_scalar)) {
+      // three / four collapsed axes, the output dense, the inner axis contiguous (or broadcast) in every operand: vectors of four
+      AxesGeom ag;
+      const mdhip_array *ops[2] = {a, b};
+      const int dts[2] = {md_dtype_of<Ts>::value, md_dtype_of<Ts>::value};
+      const size_t ess[2] = {sizeof(Ts), sizeof(Ts)};
+      if (axes_geom(it, 2, out, sizeof(To), ops, dts, ess, 2, &ag)) {
+        MD_LAUNCH((k_ew_axes<AxBinary<F>, 2, To, Ts, Tc, Ts, Tc, Ts, Tc>), md_grid_for(it.total >> 2), MD_BLOCK, ag, a->is_scalar ? nullptr : (const Ts *)a->data, sa,
+                  b->is_scalar ? nullptr : (const Ts *)b->data, sb, (const Ts *)nullptr, sb, (To *)out->data);
+        return MD_LAUNCH_CHECK("binary(axes, vectors)");
       }
     }
     // (MD_LAUNCH everywhere a call's main kernel starts: bench.py's attached events then time THAT kernel; a path that ignored them
@@ -610,6 +678,17 @@ struct HipExec {
 #undef MD_WHERE_FORM
       using Body = WhereBody<T, b8, OM_FLEX, OM_FLEX, OM_FLEX>;
       return launch_fast<Body, 1>(Body{fc, fa, fb, sc, sa, sb, o}, g, "where(fast,flex)");
+    }
+    {
+      AxesGeom ag;
+      const mdhip_array *ops[3] = {c, a, b};
+      const int dts[3] = {MDHIP_BOOL, md_dtype_of<T>::value, md_dtype_of<T>::value};
+      const size_t ess[3] = {1, sizeof(T), sizeof(T)};
+      if (axes_geom(it, 3, out, sizeof(T), ops, dts, ess, 3, &ag)) {
+        MD_LAUNCH((k_ew_axes<AxWhere, 3, T, b8, uint8_t, T, T, T, T>), md_grid_for(it.total >> 2), MD_BLOCK, ag, c->is_scalar ? nullptr : (const b8 *)c->data, sc,
+                  a->is_scalar ? nullptr : (const T *)a->data, sa, b->is_scalar ? nullptr : (const T *)b->data, sb, (T *)out->data);
+        return MD_LAUNCH_CHECK("where(axes, vectors)");
+      }
     }
     MD_LAUNCH((k_where_generic<T>), md_grid_for(it.total), MD_BLOCK, it, c->data, c->dtype, c->is_scalar, sc, a->data, a->dtype, a->is_scalar, sa, b->data,
               b->dtype, b->is_scalar, sb, (T *)out->data);

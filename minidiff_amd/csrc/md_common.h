@@ -393,5 +393,12 @@ static inline int md_build_gemm(MdGemm *g, const mdhip_array *a, const mdhip_arr
   g->a_bs = a->shape[0] == 1 ? 0 : a->strides[0]; g->a_ms = a->strides[1]; g->a_ks = a->strides[2];
   g->b_bs = b->shape[0] == 1 ? 0 : b->strides[0]; g->b_ks = b->strides[1]; g->b_ns = b->strides[2];
   g->c_bs = c->strides[0]; g->c_ms = c->strides[1]; g->c_ns = c->strides[2];
+  // (B, M, K) @ (K, N) with the batch of `a` and of `c` laid out as more rows: ONE product of B * M rows (a linear layer applied to a
+  // 3-D input; B products of M rows each fill the chip worse, M < tile height worst of all)
+  if (g->batch > 1 && g->b_bs == 0 && g->M > 0 && g->a_bs == g->M * g->a_ms && g->c_bs == g->M * g->c_ms) {
+    g->M *= g->batch;
+    g->batch = 1;
+    g->a_bs = g->c_bs = 0;
+  }
   return MDHIP_OK;
 }

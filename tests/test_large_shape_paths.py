@@ -630,6 +630,29 @@ def _three_axis_broadcasts(nd):
         np.testing.assert_array_equal(nd.add(db[sl], dy[:, :, :base[sl].shape[2]]).get(), base[sl] + y[:, :, :base[sl].shape[2]])
         np.testing.assert_array_equal(nd.true_divide(dy[:, :, :base[sl].shape[2]], db[sl]).get(), y[:, :, :base[sl].shape[2]] / base[sl])
         np.testing.assert_array_equal(nd.multiply(db[sl], db[sl]).get(), base[sl] * base[sl])
+    # unary calls, comparisons and `where` on the same iteration spaces; four axes
+    for sl in ((slice(None), slice(2, 66), slice(4, 260)), (slice(None), slice(2, 66), slice(2, 258)), (slice(None), slice(2, 66), slice(1, 257))):
+        np.testing.assert_allclose(nd.exp(db[sl]).get(), np.exp(base[sl]), rtol=1e-6)
+        np.testing.assert_array_equal(nd.absolute(db[sl]).get(), np.abs(base[sl]))
+        np.testing.assert_array_equal(nd.negative(nd.transpose(db[sl], (1, 0, 2))).get(), -base[sl].transpose(1, 0, 2))
+        np.testing.assert_array_equal(nd.greater(db[sl], dy).get(), base[sl] > y)
+        m = base[sl] > 0
+        dm = nd.asarray(m)
+        np.testing.assert_array_equal(nd.where(dm, db[sl], dy).get(), np.where(m, base[sl], y))
+        np.testing.assert_array_equal(nd.where(dm, dy, 0.0).get(), np.where(m, y, np.float32(0)))
+        np.testing.assert_array_equal(nd.where(nd.greater(dy, 0), db[sl], 1.5).get(), np.where(y > 0, base[sl], np.float32(1.5)))
+        np.testing.assert_array_equal(nd.logical_and(dm, nd.greater(dy, 0)).get(), m & (y > 0))
+        np.testing.assert_array_equal(nd.isnan(db[sl]).get(), np.isnan(base[sl]))
+    x4 = rng.standard_normal((6, 10, 12, 128)).astype(np.float32)
+    d4 = nd.asarray(x4)
+    for shp in ((1, 10, 1, 128), (6, 1, 12, 1), (1, 10, 1, 1), (6, 1, 1, 128), (6, 10, 1, 1), (10, 1, 128)):
+        o = rng.standard_normal(shp).astype(np.float32)
+        np.testing.assert_array_equal(nd.multiply(d4, nd.asarray(o)).get(), x4 * o)
+        np.testing.assert_array_equal(nd.subtract(nd.asarray(o), d4).get(), o - x4)
+        np.testing.assert_array_equal(nd.where(nd.less(d4, nd.asarray(o)), d4, nd.asarray(o)).get(), np.where(x4 < o, x4, o))
+    big4 = rng.standard_normal((6, 11, 13, 136)).astype(np.float64)
+    np.testing.assert_array_equal(nd.sqrt(nd.absolute(nd.asarray(big4)[:, 1:, 1:, 4:132])).get(), np.sqrt(np.abs(big4[:, 1:, 1:, 4:132])))
+    np.testing.assert_array_equal(nd.add(nd.asarray(big4)[:, 1:, 1:, 2:130], nd.asarray(big4)[:, :10, :12, 6:134]).get(), big4[:, 1:, 1:, 2:130] + big4[:, :10, :12, 6:134])
     # the broadcast operand is itself a broadcast view; the two big operands are different views of one base
     np.testing.assert_array_equal(nd.add(db[:, :64, :256], nd.broadcast_to(dy[:1], (8, 64, 256))).get(), base[:, :64, :256] + y[:1])
     np.testing.assert_array_equal(nd.subtract(db[:, :64, :256], db[:, 6:70, 8:264]).get(), base[:, :64, :256] - base[:, 6:70, 8:264])
@@ -647,3 +670,57 @@ def test_three_axis_broadcasts_vector_kernel_gpu(lib, on_gpu):
     assert on_gpu
     from minidiff_amd import ndarray as nd
     _three_axis_broadcasts(nd)
+
+
+def _linear_layer_on_3d_input(nd):
+    """(B, M, K) @ (K, N): the batch of a dense `a` folds into the rows of ONE product (md_build_gemm); views whose batch is not laid
+    out as more rows, a broadcast `a`, and every dtype keep the batched route. Same values either way."""
+    rng = np.random.default_rng(6)
+    for dt in (np.float32, np.float64, np.int32, np.int64):
+        def mk(*shape):
+            return (rng.standard_normal(shape) * 4).astype(dt)
+        w = mk(40, 24)
+        for a in (mk(6, 5, 40), mk(6, 1, 40), mk(1, 5, 40), mk(3, 2, 5, 40), mk(6, 10, 40)[:, ::2], mk(6, 5, 48)[:, :, 4:44], mk(5, 6, 40).transpose(1, 0, 2)):
+            ref = np.matmul(a.astype(np.float64), w.astype(np.float64))
+            da = nd.asarray(np.ascontiguousarray(a)) if a.base is None else None
+            if da is None:
+                da = nd.asarray(a)
+            got = nd.matmul(da, nd.asarray(w)).get()
+            assert got.shape == ref.shape and got.dtype == dt
+            if np.dtype(dt).kind == "f":
+                np.testing.assert_allclose(got, ref, rtol=2e-5 if dt is np.float32 else 1e-12, atol=1e-4 if dt is np.float32 else 1e-10)
+            else:
+                np.testing.assert_array_equal(got, ref.astype(dt))
+        # device-side views: a strided batch (no fold), a sliced K (fold: rows keep one stride)
+        a = mk(6, 10, 48)
+        da = nd.asarray(a)
+        for sl in ((slice(None), slice(None, None, 2), slice(4, 44)), (slice(None), slice(None), slice(0, 40)), (slice(1, 5), slice(None), slice(8, 48))):
+            got, ref = nd.matmul(da[sl], nd.asarray(w)).get(), np.matmul(a[sl].astype(np.float64), w.astype(np.float64))
+            if np.dtype(dt).kind == "f":
+                np.testing.assert_allclose(got, ref, rtol=2e-5 if dt is np.float32 else 1e-12, atol=1e-4 if dt is np.float32 else 1e-10)
+            else:
+                np.testing.assert_array_equal(got, ref.astype(dt))
+        # out= : a dense 3-D result
+        a = mk(4, 8, 40)
+        out = nd.asarray(np.zeros((4, 8, 24), dt))
+        nd.matmul(nd.asarray(a), nd.asarray(w), out=out)
+        ref = np.matmul(a.astype(np.float64), w.astype(np.float64))
+        assert np.allclose(out.get(), ref, rtol=2e-5, atol=1e-4)
+
+
+def test_linear_layer_on_3d_input_cpu(lib, on_gpu):
+    if on_gpu:
+        pytest.skip("other twin")
+    from minidiff_amd import ndarray as nd
+    _linear_layer_on_3d_input(nd)
+
+
+@pytest.mark.gpu
+def test_linear_layer_on_3d_input_gpu(lib, on_gpu):
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    _linear_layer_on_3d_input(nd)
+    rng = np.random.default_rng(7)
+    a, w = rng.standard_normal((16, 96, 512)).astype(np.float32), rng.standard_normal((512, 256)).astype(np.float32)
+    got = nd.matmul(nd.asarray(a), nd.asarray(w)).get()
+    np.testing.assert_allclose(got, np.matmul(a.astype(np.float64), w.astype(np.float64)), rtol=1e-4, atol=1e-3)
