@@ -158,6 +158,74 @@ __global__ void __launch_bounds__(MD_BLOCK) k_vm_eval_fast(MdVmDev P, To *out, i
   }
 }
 
+// Three / four collapsed axes with a contiguous (or broadcast) inner axis in every leaf — chains under the broadcasts of a
+// normalisation layer, `(x * g[:, None, :] + h[None, :, None]) ** 2` — : a lane evaluates one vector of four, the outer position from
+// two or three divisions (elementwise.hip's k_ew_axes is the eager counterpart). Interpreter only: was the one-element generic walk.
+struct VmAxes {
+  int64_t e0, e1, e2, nv, rows;
+  int64_t st[MDHIP_VM_MAX_LEAVES][3];
+};
+template <class T> struct AxesLoader {
+  const MdVmDev &P;
+  const VmAxes &A;
+  int64_t r0, r1, r2, c;
+  template <class S> __device__ __forceinline__ void vec(const MdVmLeaf &L, int64_t off, T (&d)[4]) const {
+    const MdVec<S, 4> v = *reinterpret_cast<const MdVec<S, 4> *>((const S *)L.p + off + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (md_same<S, uint8_t>::value) d[j] = (T)(v.v[j] != 0);
+      else d[j] = (T)v.v[j];
+    }
+  }
+  __device__ __forceinline__ void operator()(int l, T (&d)[4]) const {
+    const MdVmLeaf &L = P.leaf[l];
+    const int64_t off = r0 * A.st[l][0] + r1 * A.st[l][1] + r2 * A.st[l][2];
+    if (L.is) {
+      switch (L.dtype) {
+        case MDHIP_F32: vec<float>(L, off, d); break;
+        case MDHIP_F64: vec<double>(L, off, d); break;
+        case MDHIP_BOOL: vec<uint8_t>(L, off, d); break;
+        case MDHIP_I32: vec<int32_t>(L, off, d); break;
+        default: vec<int64_t>(L, off, d); break;
+      }
+    } else {
+      const T s = md_load<T>(L.p, L.dtype, off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = s;
+    }
+  }
+};
+template <class T, class To>
+__global__ void __launch_bounds__(MD_BLOCK) k_vm_eval_axes(MdVmDev P, VmAxes A, To *out) {
+  MD_VM_PROLOGUE;
+  const int64_t total = A.rows * A.nv, gs = (int64_t)gridDim.x * blockDim.x;
+  const bool narrow = total < (1ll << 31);
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gs) {
+    int64_t row, r0 = 0, r1, r2;
+    if (narrow) {
+      const uint32_t w = (uint32_t)v / (uint32_t)A.nv, q = w / (uint32_t)A.e2;
+      row = w;
+      r2 = w - q * (uint32_t)A.e2;
+      r1 = q;
+      if (A.e0 != 1) { const uint32_t t = q / (uint32_t)A.e1; r0 = t; r1 = q - t * (uint32_t)A.e1; }
+    } else {
+      row = v / A.nv;
+      const int64_t q = row / A.e2;
+      r2 = row - q * A.e2;
+      r1 = q;
+      if (A.e0 != 1) { r0 = q / A.e1; r1 = q - r0 * A.e1; }
+    }
+    const int64_t c = (v - row * A.nv) << 2;
+    AxesLoader<T> ld{P, A, r0, r1, r2, c};
+    T r[4];
+    md_vm_run<T, 4>(P.n_instr, fetch, ld, r);
+    MdVec<To, 4> o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = md_cast<To>(r[j]);
+    *reinterpret_cast<MdVec<To, 4> *>(out + row * (A.nv << 2) + c) = o;
+  }
+}
+
 template <class T, class To>
 __global__ void __launch_bounds__(MD_BLOCK) k_vm_eval_generic(MdVmDev P, MdVmIter it, To *out) {
   MD_VM_PROLOGUE;
@@ -348,6 +416,38 @@ static bool fast_geometry(const MdVmIter &it, int n_leaves, const mdhip_vm_progr
   return true;
 }
 
+// k_vm_eval_axes eligibility (the conditions of elementwise.hip's axes_geom, per leaf); fills leaf `is` and the stride table
+static bool axes_geometry(const MdVmIter &it, const mdhip_vm_program *pr, const mdhip_array *out, MdVmDev *D, VmAxes *A) {
+  if (it.ndim != 3 && it.ndim != 4) return false;
+  const int nd = it.ndim, sh = 4 - nd, O = MDHIP_VM_MAX_LEAVES;
+  const int64_t inner = it.shape[nd - 1];
+  if ((inner & 3) || it.total < (1 << 16) || it.strides[O][nd - 1] != 1 || !al_for(out->data, out->dtype)) return false;
+  int64_t dense = inner;
+  for (int d = nd - 2; d >= 0; --d) {
+    if (it.strides[O][d] != dense) return false;
+    dense *= it.shape[d];
+  }
+  memset(A, 0, sizeof *A);
+  A->e0 = nd == 4 ? it.shape[0] : 1;
+  A->e1 = it.shape[1 - sh];
+  A->e2 = it.shape[2 - sh];
+  A->nv = inner >> 2;
+  A->rows = A->e0 * A->e1 * A->e2;
+  for (int l = 0; l < pr->n_leaves; ++l) {
+    const int64_t is = it.strides[l][nd - 1];
+    if (is != 0 && is != 1) return false;
+    if (is == 1 && !al_for(pr->leaves[l].data, pr->leaves[l].dtype)) return false;
+    for (int j = sh; j < 3; ++j) {
+      const int64_t st = it.strides[l][j - sh];
+      if (is == 1 && (st & 3)) return false;
+      A->st[l][j] = st;
+    }
+    D->leaf[l].os = 0;
+    D->leaf[l].is = (int32_t)is;
+  }
+  return true;
+}
+
 template <class T> static int eval_typed(const mdhip_vm_program *pr, const mdhip_array *out) {
   MdVmIter it;
   MD_TRY(md_vm_build_iter(&it, pr, out, out));
@@ -382,6 +482,12 @@ template <class T> static int eval_typed(const mdhip_vm_program *pr, const mdhip
     if (to_bool) k_vm_eval_fast<T, b8><<<md_grid_for(work), MD_BLOCK, 0, st>>>(D, (b8 *)out->data, rows, inner);
     else k_vm_eval_fast<T, T><<<md_grid_for(work), MD_BLOCK, 0, st>>>(D, (T *)out->data, rows, inner);
     return MD_LAUNCH_CHECK("vm_eval(fast)");
+  }
+  VmAxes A;
+  if (axes_geometry(it, pr, out, &D, &A)) {
+    if (to_bool) k_vm_eval_axes<T, b8><<<md_grid_for(it.total >> 2), MD_BLOCK, 0, st>>>(D, A, (b8 *)out->data);
+    else k_vm_eval_axes<T, T><<<md_grid_for(it.total >> 2), MD_BLOCK, 0, st>>>(D, A, (T *)out->data);
+    return MD_LAUNCH_CHECK("vm_eval(axes)");
   }
   if (to_bool) k_vm_eval_generic<T, b8><<<md_grid_for(it.total), MD_BLOCK, 0, st>>>(D, it, (b8 *)out->data);
   else k_vm_eval_generic<T, T><<<md_grid_for(it.total), MD_BLOCK, 0, st>>>(D, it, (T *)out->data);

@@ -25,10 +25,16 @@ class CapturedSweep:
             step()
         self._lib.sync()
         handle = C.c_void_p()
+        # A capture records the kernels that are LAUNCHED between begin and end. In lazy mode a result still pending when the step
+        # returns would be launched later, outside the graph, and every replay would miss it (a training loop replayed with
+        # MDHIP_LAZY=1 drifted from its third sweep on): the recorded step runs eagerly; lazy mode comes back afterwards.
+        from . import ndarray as _nd
+        was_lazy = _nd.set_lazy(False)
         self._lib.graph_begin()
         try:
             self.outputs = step()
         except BaseException:
+            _nd.set_lazy(was_lazy)
             try:
                 self._lib.graph_end(C.byref(handle))
             except RuntimeError:
@@ -40,6 +46,7 @@ class CapturedSweep:
                     pass
             self._graph = None
             raise
+        _nd.set_lazy(was_lazy)
         self._lib.graph_end(C.byref(handle))
         self._graph = handle
         self.replays = 0
@@ -111,6 +118,8 @@ class SegmentedSweep:
 
         for n in names:
             setattr(comm, n, cut(originals[n]))
+        from . import ndarray as _nd
+        was_lazy = _nd.set_lazy(False)     # (as in CapturedSweep: nothing may stay pending past the end of a segment)
         self._lib.graph_begin()
         try:
             self.outputs = sweep()
@@ -126,6 +135,7 @@ class SegmentedSweep:
             self.close()
             raise
         finally:
+            _nd.set_lazy(was_lazy)
             for n in names:   # put back exactly what was there: an instance attribute is restored, a class method is uncovered
                 if was_instance_attr[n]:
                     setattr(comm, n, originals[n])

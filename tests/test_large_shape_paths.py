@@ -653,6 +653,31 @@ def _three_axis_broadcasts(nd):
     big4 = rng.standard_normal((6, 11, 13, 136)).astype(np.float64)
     np.testing.assert_array_equal(nd.sqrt(nd.absolute(nd.asarray(big4)[:, 1:, 1:, 4:132])).get(), np.sqrt(np.abs(big4[:, 1:, 1:, 4:132])))
     np.testing.assert_array_equal(nd.add(nd.asarray(big4)[:, 1:, 1:, 2:130], nd.asarray(big4)[:, :10, :12, 6:134]).get(), big4[:, 1:, 1:, 2:130] + big4[:, :10, :12, 6:134])
+    # fused chains (lazy mode) on the same iteration spaces: the interpreter's vector kernel for three / four axes
+    was = nd.lazy_enabled() if hasattr(nd, "lazy_enabled") else None
+    nd.set_lazy(True)
+    try:
+        g = rng.standard_normal((8, 1, 256)).astype(np.float32)
+        h = rng.standard_normal((1, 64, 1)).astype(np.float32)
+        dg, dh = nd.asarray(g), nd.asarray(h)
+        for sl in ((slice(None), slice(2, 66), slice(4, 260)), (slice(None), slice(2, 66), slice(1, 257)), (slice(None), slice(0, 64), slice(0, 256))):
+            xs = base[sl]
+            got = nd.materialize(nd.power(nd.add(nd.multiply(db[sl], dg), dh), 2)).get()
+            np.testing.assert_allclose(got, (xs * g + h) ** 2, rtol=1e-6, atol=1e-6)
+            got = nd.materialize(nd.where(nd.greater(db[sl], dg), nd.subtract(db[sl], dh), nd.negative(dg))).get()
+            np.testing.assert_array_equal(got, np.where(xs > g, xs - h, -g))
+            got = nd.materialize(nd.greater(nd.add(db[sl], dh), dg)).get()
+            np.testing.assert_array_equal(got, (xs + h) > g)
+        o4 = rng.standard_normal((1, 10, 1, 128)).astype(np.float32)
+        p4 = rng.standard_normal((6, 1, 12, 1)).astype(np.float32)
+        got = nd.materialize(nd.multiply(nd.subtract(d4, nd.asarray(o4)), nd.asarray(p4))).get()
+        np.testing.assert_array_equal(got, (x4 - o4) * p4)
+        i3 = rng.integers(-50, 50, (8, 64, 256)).astype(np.int64)
+        j3 = rng.integers(-50, 50, (8, 1, 256)).astype(np.int32)
+        got = nd.materialize(nd.add(nd.multiply(nd.asarray(i3), nd.asarray(j3)), 3)).get()
+        np.testing.assert_array_equal(got, i3 * j3 + 3)
+    finally:
+        nd.set_lazy(False if was is None else was)
     # the broadcast operand is itself a broadcast view; the two big operands are different views of one base
     np.testing.assert_array_equal(nd.add(db[:, :64, :256], nd.broadcast_to(dy[:1], (8, 64, 256))).get(), base[:, :64, :256] + y[:1])
     np.testing.assert_array_equal(nd.subtract(db[:, :64, :256], db[:, 6:70, 8:264]).get(), base[:, :64, :256] - base[:, 6:70, 8:264])

@@ -77,14 +77,22 @@ def test_training_loop_matches_numpy_engine_gpu(lib, on_gpu, lazy):
 
 
 @gpu
-def test_training_loop_replayed_from_a_graph_gpu(lib, on_gpu):
+@pytest.mark.parametrize("lazy", [False, True], ids=["eager", "lazy"])
+def test_training_loop_replayed_from_a_graph_gpu(lib, on_gpu, lazy):
+    """(lazy: the recorded sweep runs eagerly — a result left pending past the end of the capture would be missing from every replay)"""
     assert on_gpu
+    from minidiff_amd import ndarray as nd
     from minidiff_amd.graph import SweepCache
     dev, ref = _engines(lib)
     l_ref, p_ref = _loop(ref, 40)
-    with SweepCache(dev, validate_every=0) as cache:
-        l_dev, p_dev = _loop(dev, 40, cache=cache)
-        assert cache.stats["captured"] == 1 and cache.stats["replayed"] >= 35 and cache.stats["uncapturable"] == 0, cache.stats
+    prev = nd.set_lazy(lazy)
+    try:
+        with SweepCache(dev, validate_every=0) as cache:
+            l_dev, p_dev = _loop(dev, 40, cache=cache)
+            assert cache.stats["captured"] == 1 and cache.stats["replayed"] >= 35 and cache.stats["uncapturable"] == 0, cache.stats
+        assert nd.lazy_enabled() is lazy
+    finally:
+        nd.set_lazy(prev)
     assert np.allclose(l_dev, l_ref, rtol=2e-5, atol=2e-5)
     for a, b in zip(p_dev, p_ref):
         assert np.allclose(a, b, rtol=4e-4, atol=4e-4)
