@@ -968,7 +968,10 @@ struct HipExec {
     }
     // (kept last axis contiguous, >= 64 outputs: the column kernels, whatever the width — up to round 4 widths under 1024 went to a
     // block per OUTPUT walking its column with the row stride: the bias gradient of a 300,000 x 1000 batch ran at 550 GB/s)
-    if (cols_ok && (sizeof(Tacc) >= 4 || !rows_ok || n_out >= 256)) {   // (1-byte accumulators — any / all — from 256 columns on)
+    // (under 1024 outputs only when the contiguous kept axis is at least a wave wide: the middle axis of 8 x 62500 x 8 has 64 outputs in
+    // runs of 8 — one block, a quarter of its lanes, 0.24 ms; a block per output walks them in 0.03)
+    const bool wide = pl.nk >= 1 && pl.kshape[pl.nk - 1] >= 64;
+    if (cols_ok && (!rows_ok || n_out >= 1024 || (wide && (sizeof(Tacc) >= 4 || n_out >= 256)))) {   // (1-byte accumulators — any / all — from 256 columns on)
       if constexpr (sizeof(Tacc) >= 4 && md_same<Tacc, To>::value) {
         constexpr int V = 16 / sizeof(Tacc);
         const bool vec_ok = pl.nk == 1 && pl.nr == 1 && pl.ko[0] == 1 && x->dtype == md_dtype_of<Tacc>::value &&

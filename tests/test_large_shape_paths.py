@@ -749,3 +749,31 @@ def test_linear_layer_on_3d_input_gpu(lib, on_gpu):
     a, w = rng.standard_normal((16, 96, 512)).astype(np.float32), rng.standard_normal((512, 256)).astype(np.float32)
     got = nd.matmul(nd.asarray(a), nd.asarray(w)).get()
     np.testing.assert_allclose(got, np.matmul(a.astype(np.float64), w.astype(np.float64)), rtol=1e-4, atol=1e-3)
+
+
+def _middle_axis_narrow_inner(nd):
+    """Reductions over the middle axis of (8, n, 8) / (3, n, 100) / (40, n, 40): few outputs in short contiguous runs (block per output),
+    a wave-wide kept axis (column kernels), many outputs — same values whichever kernel the dispatch picks."""
+    rng = np.random.default_rng(8)
+    for shp in ((8, 6250, 8), (3, 3000, 100), (40, 700, 40), (2, 5000, 64), (1, 9000, 63)):
+        for dt in (np.float32, np.int64, np.bool_):
+            a = (rng.integers(-4, 5, shp)).astype(dt)
+            d = nd.asarray(a)
+            for name in ("sum", "max", "min", "any"):
+                got, ref = getattr(nd, name)(d, axis=1).get(), getattr(np, name)(a, axis=1)
+                assert got.dtype == ref.dtype and np.array_equal(got, ref), (shp, dt, name)
+            np.testing.assert_array_equal(nd.sum(d, axis=1, keepdims=True).get(), np.sum(a, axis=1, keepdims=True))
+
+
+def test_middle_axis_narrow_inner_cpu(lib, on_gpu):
+    if on_gpu:
+        pytest.skip("other twin")
+    from minidiff_amd import ndarray as nd
+    _middle_axis_narrow_inner(nd)
+
+
+@pytest.mark.gpu
+def test_middle_axis_narrow_inner_gpu(lib, on_gpu):
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    _middle_axis_narrow_inner(nd)
