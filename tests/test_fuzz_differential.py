@@ -73,3 +73,19 @@ def test_fuzz_lazy_cpu(lib, on_gpu):
         assert fuzz_device.main(400, 305, False) == 0
     finally:
         nd.set_lazy(prev)
+
+
+import fuzz_axes  # noqa: E402
+
+
+def test_fuzz_axes_cpu(lib, on_gpu):
+    """Three- / four-axis iteration spaces (broadcast, sliced, axis-swapped operands), eager and fused (tests/fuzz_axes.py)."""
+    if on_gpu:
+        pytest.skip("other twin")
+    assert fuzz_axes.main(160, 401) == 0
+
+
+@pytest.mark.gpu
+def test_fuzz_axes_gpu(lib, on_gpu):
+    assert on_gpu
+    assert fuzz_axes.main(1200, 402) == 0
