@@ -1948,7 +1948,7 @@ def _arg_reduce(code, a, axis, keepdims):
             res = reshape(res, (1,) * a.ndim)
         return res
     ax = normalize_axis(int(axis), a.ndim) if a.ndim else int(axis)
-    if a.ndim >= 2 and a._expr is None and a.shape[ax] >= 65536 and a.size // a.shape[ax] <= 64 and a._strides[ax] != 1:
+    if a.ndim >= 2 and a._expr is None and a.shape[ax] >= 16384 and a.size // a.shape[ax] <= 64 and a._strides[ax] != 1:
         # a handful of LONG strided lines (argmax down the two columns of a 2,000,000 x 2 array: 4.3 ms on the column-strips kernel, which
         # finds its parallelism across columns): gather the lines into rows first — 16 MB copied in 0.05 ms — and search each row
         perm = [d for d in range(a.ndim) if d != ax] + [ax]
