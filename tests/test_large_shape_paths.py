@@ -605,7 +605,7 @@ def test_few_tiles_long_k_products_gpu(lib, on_gpu):
 
 def _three_axis_broadcasts(nd):
     """(B, R, C) op (B, 1, C) / (1, R, 1) / a sliced (B, R, C) view: iteration spaces that keep three axes take the 16-byte
-    vector kernel of elementwise.hip (k_binary_rows3); bit-identical to NumPy in every loop dtype it serves, both operand orders,
+    vector kernel of elementwise.hip (k_ew_axes); bit-identical to NumPy in every loop dtype it serves, both operand orders,
     and the shapes next to its conditions (inner extent not a multiple of 4, misaligned base, small totals) still agree."""
     rng = np.random.default_rng(5)
     for dt in (np.float32, np.float64, np.int32, np.int64):
