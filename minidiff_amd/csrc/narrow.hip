@@ -55,6 +55,52 @@ template <class F, class Tc, class S> struct nw_out1 {
   using type = typename md_cond<md_same<R, b8>::value, b8, S>::type;
 };
 
+// ------------------------------------------------------- broadcasts, 16-B vectors ----
+// Two to four collapsed axes with the inner axis contiguous or broadcast in every operand ((R, C) + (C,), (B, R, C) * (B, 1, C) in
+// float16 / int8 ..): a lane owns one 16-B vector of the OUTPUT's storage type count (8 float16, 16 int8 ..); the scheme of
+// elementwise.hip's k_ew_axes. Was the one-element generic kernel (~350 GB/s).
+struct NwAxes {
+  int64_t e0, e1, e2, nv, rows;
+  int64_t st[2][3];
+  int in[2];
+};
+template <class F, class Tc, class S>
+__global__ void __launch_bounds__(MD_BLOCK) k_nw_binary_axes(NwAxes g, const S *__restrict__ a, const S *__restrict__ b, Tc sa, Tc sb,
+                                                            typename nw_out<F, Tc, S>::type *__restrict__ out) {
+  using So = typename nw_out<F, Tc, S>::type;
+  constexpr int E = 16 / sizeof(S);
+  typedef MdVec<S, E> Vin;
+  typedef MdVec<So, E> Vout;
+  const int64_t total = g.rows * g.nv, gs = (int64_t)gridDim.x * MD_BLOCK;
+  auto load = [&](const S *p, Tc s, int in, int64_t off, int64_t c, Tc (&r)[E]) {
+    if (p == nullptr) {
+#pragma unroll
+      for (int j = 0; j < E; ++j) r[j] = s;
+    } else if (in) {
+      const Vin t = *reinterpret_cast<const Vin *>(p + off + c);
+#pragma unroll
+      for (int j = 0; j < E; ++j) r[j] = md_cast<Tc>(t.v[j]);
+    } else {
+      const Tc t = md_cast<Tc>(p[off]);
+#pragma unroll
+      for (int j = 0; j < E; ++j) r[j] = t;
+    }
+  };
+  for (int64_t v = (int64_t)blockIdx.x * MD_BLOCK + threadIdx.x; v < total; v += gs) {
+    const int64_t row = v / g.nv, q = row / g.e2, r2 = row - q * g.e2;
+    int64_t r0 = 0, r1 = q;
+    if (g.e0 != 1) { r0 = q / g.e1; r1 = q - r0 * g.e1; }
+    const int64_t c = (v - row * g.nv) * E;
+    Tc x[E], y[E];
+    load(a, sa, g.in[0], r0 * g.st[0][0] + r1 * g.st[0][1] + r2 * g.st[0][2], c, x);
+    load(b, sb, g.in[1], r0 * g.st[1][0] + r1 * g.st[1][1] + r2 * g.st[1][2], c, y);
+    Vout o;
+#pragma unroll
+    for (int j = 0; j < E; ++j) o.v[j] = md_cast<So>(F::apply(x[j], y[j]));
+    *reinterpret_cast<Vout *>(out + row * (g.nv * E) + c) = o;
+  }
+}
+
 // ------------------------------------------------------------------- stream ----
 template <class F, class Tc, class S, int MA, int MB, bool NT>
 __global__ void __launch_bounds__(MD_BLOCK) k_nw_binary(const S *__restrict__ a, const S *__restrict__ b, Tc sa, Tc sb,
@@ -241,6 +287,43 @@ struct HipExecN {
     if (!a->is_scalar) return binary_stream<F, Tc, DT, NM_VEC, NM_SCAL>(a, b, sa, sb, out, n);
     return binary_stream<F, Tc, DT, NM_SCAL, NM_VEC>(a, b, sa, sb, out, n);
   }
+  // -1: the iteration space does not fit k_nw_binary_axes (the caller goes on to the generic kernel)
+  template <class F, class Tc, int DT>
+  static int binary_axes(const MdIter &it, const mdhip_array *a, const mdhip_array *b, Tc sa, Tc sb, const mdhip_array *out) {
+    using S = typename nw_storage<DT>::type;
+    using So = typename nw_out<F, Tc, S>::type;
+    constexpr int E = 16 / sizeof(S);
+    const int nd = it.ndim, sh = 4 - nd;
+    const int64_t inner = it.shape[nd - 1];
+    if ((inner % E) || it.strides[2][nd - 1] != 1 || ((uintptr_t)out->data % (sizeof(So) * E)) != 0) return -1;
+    int64_t dense = inner;
+    for (int d = nd - 2; d >= 0; --d) {
+      if (it.strides[2][d] != dense) return -1;
+      dense *= it.shape[d];
+    }
+    NwAxes g{};
+    g.e0 = nd == 4 ? it.shape[0] : 1;
+    g.e1 = nd >= 3 ? it.shape[nd - 3] : 1;
+    g.e2 = it.shape[nd - 2];
+    g.nv = inner / E;
+    g.rows = g.e0 * g.e1 * g.e2;
+    const mdhip_array *ops[2] = {a, b};
+    for (int k = 0; k < 2; ++k) {
+      if (ops[k]->is_scalar) continue;
+      const int64_t is = it.strides[k][nd - 1];
+      if (is != 0 && is != 1) return -1;
+      g.in[k] = (int)is;
+      for (int j = sh; j < 3; ++j) {
+        const int64_t st = it.strides[k][j - sh];
+        if (is == 1 && (st % E)) return -1;
+        g.st[k][j] = st;
+      }
+      if (is == 1 && ((uintptr_t)ops[k]->data & 15)) return -1;
+    }
+    MD_LAUNCH((k_nw_binary_axes<F, Tc, S>), md_grid_for(g.rows * g.nv), MD_BLOCK, g, a->is_scalar ? nullptr : (const S *)a->data,
+              b->is_scalar ? nullptr : (const S *)b->data, sa, sb, (So *)out->data);
+    return MD_LAUNCH_CHECK("binary(narrow, axes)");
+  }
   template <class F, class Tc> static int nbinary(const MdIter &it, const mdhip_array *a, const mdhip_array *b, const mdhip_array *out) {
     using R = decltype(F::apply(Tc(), Tc()));
     const Tc sa = a->is_scalar ? md_scalar_as<Tc>(a) : Tc(), sb = b->is_scalar ? md_scalar_as<Tc>(b) : Tc();
@@ -256,6 +339,20 @@ struct HipExecN {
     break;
         MD_NW_B(MDHIP_I8) MD_NW_B(MDHIP_I16) MD_NW_B(MDHIP_U8) MD_NW_B(MDHIP_U16) MD_NW_B(MDHIP_U32) MD_NW_B(MDHIP_U64) MD_NW_B(MDHIP_F16)
 #undef MD_NW_B
+      }
+    }
+    if (same && md_is_narrow(sdt) && (md_same<R, b8>::value ? out->dtype == MDHIP_BOOL : out->dtype == sdt) && it.ndim >= 2 && it.ndim <= 4 &&
+        it.total >= (1 << 14)) {
+      switch (sdt) {
+#define MD_NW_BA(DT)                                                                                                                  \
+  case DT:                                                                                                                            \
+    if constexpr (md_same<Tc, typename md_carrier_type<DT>::type>::value) {                                                           \
+      int rc = binary_axes<F, Tc, DT>(it, a, b, sa, sb, out);                                                                         \
+      if (rc != -1) return rc;                                                                                                        \
+    }                                                                                                                                 \
+    break;
+        MD_NW_BA(MDHIP_I8) MD_NW_BA(MDHIP_I16) MD_NW_BA(MDHIP_U8) MD_NW_BA(MDHIP_U16) MD_NW_BA(MDHIP_U32) MD_NW_BA(MDHIP_U64) MD_NW_BA(MDHIP_F16)
+#undef MD_NW_BA
       }
     }
     k_nw_binary_generic<F, Tc><<<md_grid_for(it.total), MD_BLOCK, 0, md_stream()>>>(it, a->data, a->dtype, a->is_scalar, sa, b->data, b->dtype,

@@ -777,3 +777,52 @@ def test_middle_axis_narrow_inner_gpu(lib, on_gpu):
     assert on_gpu
     from minidiff_amd import ndarray as nd
     _middle_axis_narrow_inner(nd)
+
+
+def _narrow_broadcasts(nd):
+    """Storage-only dtypes under broadcasts (narrow.hip k_nw_binary_axes): row vectors, (B, 1, C), (1, R, 1), four axes, sliced views with
+    aligned and misaligned offsets, comparisons (bool results), scalars — bit-identical to NumPy."""
+    rng = np.random.default_rng(9)
+    for dt in (np.float16, np.int8, np.uint8, np.int16, np.uint16, np.uint32, np.uint64):
+        def mk(*shape):
+            if np.dtype(dt).kind == "f":
+                return (rng.standard_normal(shape) * 4).astype(dt)
+            return rng.integers(0, 100, shape).astype(dt)
+        for shape, others in (((96, 256), [(256,), (96, 1), (1, 256)]), ((6, 40, 128), [(6, 1, 128), (1, 40, 1), (40, 128), (6, 40, 1)]),
+                              ((3, 4, 20, 64), [(1, 4, 1, 64), (3, 1, 20, 1)]), ((70, 250), [(250,)]), ((64, 264), [(264,)])):
+            x = mk(*shape)
+            dx = nd.asarray(x)
+            for oshape in others:
+                o = mk(*oshape)
+                do = nd.asarray(o)
+                with np.errstate(all="ignore"):
+                    for name in ("add", "multiply", "maximum", "less", "not_equal"):
+                        want, got = getattr(np, name)(x, o), getattr(nd, name)(dx, do).get()
+                        assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), (dt, name, shape, oshape)
+                        want, got = getattr(np, name)(o, x), getattr(nd, name)(do, dx).get()
+                        assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), (dt, name, oshape, shape)
+        base = mk(6, 44, 160)
+        db = nd.asarray(base)
+        y = mk(6, 1, 128)
+        dy = nd.asarray(y)
+        for sl in ((slice(None), slice(2, 42), slice(16, 144)), (slice(None), slice(2, 42), slice(1, 129)), (slice(None), slice(0, 40), slice(8, 136)),
+                   (slice(None), slice(None, None, -1), slice(32, 160))):
+            ys = y if base[sl].shape[1] == 40 else y
+            with np.errstate(all="ignore"):
+                np.testing.assert_array_equal(nd.add(db[sl], dy).get(), base[sl] + ys)
+                np.testing.assert_array_equal(nd.greater_equal(dy, db[sl]).get(), ys >= base[sl])
+                np.testing.assert_array_equal(nd.subtract(db[sl], db[sl]).get(), base[sl] - base[sl])
+
+
+def test_narrow_broadcasts_cpu(lib, on_gpu):
+    if on_gpu:
+        pytest.skip("other twin")
+    from minidiff_amd import ndarray as nd
+    _narrow_broadcasts(nd)
+
+
+@pytest.mark.gpu
+def test_narrow_broadcasts_gpu(lib, on_gpu):
+    assert on_gpu
+    from minidiff_amd import ndarray as nd
+    _narrow_broadcasts(nd)
